@@ -1,0 +1,336 @@
+"""CPU ORACLE bindings -- test infrastructure, NOT product code.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module.  ``hackathonopticalflow_amd`` never does.
+
+Two things live here:
+
+* ctypes bindings to ``oracle/_build/libofarn_oracle*.so`` (farneback_oracle.c / filter_oracle.c),
+  the plain-C restatement of OpenCV 4.10's CPU Farneback that the reference reaches through
+  ``cv2.calcOpticalFlowFarneback`` (DenseOF.py:147-156).  PARITY UNPINNED -- see the C header.
+* the reference's own NumPy lines for the measurement grid, the vector filter and the danger
+  brightness, re-typed from pathfinder_viewer.py:159-176, 204-217, 252-267 and executed by the
+  real NumPy, so their float32/float64 promotion semantics are the reference's.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+
+BOX_RUNNING = 0  # OpenCV's literal running-sum order
+BOX_DIRECT = 1   # direct fixed-order window sums (the order the HIP kernels use)
+
+
+class OfoParams(C.Structure):
+    _fields_ = [("pyr_scale", C.c_double), ("levels", C.c_int), ("winsize", C.c_int),
+                ("iterations", C.c_int), ("poly_n", C.c_int), ("poly_sigma", C.c_double),
+                ("flags", C.c_int)]
+
+
+class OfoCapture(C.Structure):
+    _fields_ = [(n, C.POINTER(C.POINTER(C.c_float)))
+                for n in ("I0", "I1", "R0", "R1", "M_first", "flow_init", "flow_out")]
+
+
+def build(force: bool = False) -> None:
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    so = os.path.join(_BUILD, "libofarn_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("farneback_oracle.c", "filter_oracle.c", "Makefile")]
+    if (not force and os.path.exists(so)
+            and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs)
+            and os.path.exists(os.path.join(_BUILD, "libofarn_oracle_omp.so"))):
+        return
+    subprocess.run(["make", "-C", _HERE, "-s", "all"], check=True)
+
+
+_libs: dict[bool, C.CDLL] = {}
+
+
+def lib(omp: bool = False) -> C.CDLL:
+    if omp not in _libs:
+        build()
+        l = C.CDLL(os.path.join(_BUILD, "libofarn_oracle_omp.so" if omp else "libofarn_oracle.so"))
+        fp, u8p, ip, dp = (C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int),
+                           C.POINTER(C.c_double))
+        l.ofo_crop_levels.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int]
+        l.ofo_crop_levels.restype = C.c_int
+        l.ofo_level_geom.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, ip, ip, dp, ip]
+        l.ofo_level_geom.restype = None
+        l.ofo_gaussian_kernel.argtypes = [C.c_int, C.c_double, fp]
+        l.ofo_gaussian_blur.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_double, fp]
+        l.ofo_gaussian_blur.restype = None
+        l.ofo_resize_linear.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int]
+        l.ofo_resize_linear.restype = None
+        l.ofo_level_image.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                      C.c_int, C.c_int, fp]
+        l.ofo_level_image.restype = None
+        l.ofo_poly_prepare.argtypes = [C.c_int, C.c_double, fp, fp, fp, dp]
+        l.ofo_poly_prepare.restype = None
+        l.ofo_polyexp.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_double, fp]
+        l.ofo_polyexp.restype = None
+        l.ofo_update_matrices.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int]
+        l.ofo_update_matrices.restype = None
+        l.ofo_update_flow_blur.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        l.ofo_update_flow_blur.restype = None
+        l.ofo_farneback_ex.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.POINTER(OfoParams),
+                                       C.c_int, fp, C.POINTER(OfoCapture)]
+        l.ofo_farneback_ex.restype = C.c_int
+        l.ofo_farneback_batch.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(OfoParams), C.c_int, fp, C.c_int]
+        l.ofo_farneback_batch.restype = C.c_int
+        l.ofo_max_threads.restype = C.c_int
+        l.ofo_grid_points.argtypes = [C.c_int, C.c_int, C.c_int, fp]
+        l.ofo_grid_points.restype = C.c_int
+        l.ofo_vector_filter.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, u8p, fp,
+                                        C.POINTER(C.c_int32), u8p, dp]
+        l.ofo_vector_filter.restype = C.c_int
+        _libs[omp] = l
+    return _libs[omp]
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u8p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _params(pyr_scale=0.5, levels=3, winsize=15, iterations=3, poly_n=5, poly_sigma=1.2, flags=0):
+    return OfoParams(float(pyr_scale), int(levels), int(winsize), int(iterations), int(poly_n),
+                     float(poly_sigma), int(flags))
+
+
+# --------------------------------------------------------------------------- geometry
+def crop_levels(W, H, pyr_scale, levels) -> int:
+    return lib().ofo_crop_levels(W, H, pyr_scale, levels)
+
+
+def level_geom(W, H, pyr_scale, k):
+    w, h, ks, sg = C.c_int(), C.c_int(), C.c_int(), C.c_double()
+    lib().ofo_level_geom(W, H, pyr_scale, k, C.byref(w), C.byref(h), C.byref(sg), C.byref(ks))
+    return w.value, h.value, sg.value, ks.value
+
+
+# --------------------------------------------------------------------------- stages
+def gaussian_kernel(n, sigma):
+    out = np.empty(n, np.float32)
+    lib().ofo_gaussian_kernel(n, sigma, _fp(out))
+    return out
+
+
+def gaussian_blur(img_f32, ksize, sigma):
+    src = np.ascontiguousarray(img_f32, np.float32)
+    dst = np.empty_like(src)
+    lib().ofo_gaussian_blur(_fp(src), src.shape[1], src.shape[0], ksize, sigma, _fp(dst))
+    return dst
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, np.float32)
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    dst = np.empty((dh, dw) if src.ndim == 2 else (dh, dw, cn), np.float32)
+    lib().ofo_resize_linear(_fp(src), src.shape[1], src.shape[0], cn, _fp(dst), dw, dh)
+    return dst
+
+
+def level_image(img_u8, ksize, sigma, w, h):
+    img = np.ascontiguousarray(img_u8, np.uint8)
+    out = np.empty((h, w), np.float32)
+    lib().ofo_level_image(_u8p(img), img.shape[1], img.shape[0], img.shape[1], ksize, sigma, w, h, _fp(out))
+    return out
+
+
+def poly_prepare(n, sigma):
+    g = np.zeros(2 * n + 1, np.float32)
+    xg = np.zeros_like(g)
+    xxg = np.zeros_like(g)
+    ig = np.zeros(4, np.float64)
+    off = n * 4  # bytes to the centre element
+    cast = lambda a: C.cast(a.ctypes.data + off, C.POINTER(C.c_float))
+    lib().ofo_poly_prepare(n, sigma, cast(g), cast(xg), cast(xxg), ig.ctypes.data_as(C.POINTER(C.c_double)))
+    return g, xg, xxg, ig
+
+
+def polyexp(I, n=5, sigma=1.2):
+    I = np.ascontiguousarray(I, np.float32)
+    R = np.empty(I.shape + (5,), np.float32)
+    lib().ofo_polyexp(_fp(I), I.shape[1], I.shape[0], n, sigma, _fp(R))
+    return R
+
+
+def update_matrices(R0, R1, flow):
+    R0 = np.ascontiguousarray(R0, np.float32)
+    R1 = np.ascontiguousarray(R1, np.float32)
+    flow = np.ascontiguousarray(flow, np.float32)
+    h, w = flow.shape[:2]
+    M = np.empty((h, w, 5), np.float32)
+    lib().ofo_update_matrices(_fp(R0), _fp(R1), _fp(flow), _fp(M), w, h, 0, h)
+    return M
+
+
+def update_flow_blur(R0, R1, flow, M, winsize, update_matrices_flag, box_mode=BOX_RUNNING):
+    """Returns (new_flow, new_M); inputs are not modified."""
+    R0 = np.ascontiguousarray(R0, np.float32)
+    R1 = np.ascontiguousarray(R1, np.float32)
+    flow = np.array(flow, np.float32, order="C", copy=True)
+    M = np.array(M, np.float32, order="C", copy=True)
+    h, w = flow.shape[:2]
+    lib().ofo_update_flow_blur(_fp(R0), _fp(R1), _fp(flow), _fp(M), w, h, winsize,
+                               int(bool(update_matrices_flag)), box_mode)
+    return flow, M
+
+
+@dataclass
+class Capture:
+    I0: list
+    I1: list
+    R0: list
+    R1: list
+    M_first: list
+    flow_init: list
+    flow_out: list
+
+
+def farneback(prev, next, pyr_scale=0.5, levels=3, winsize=15, iterations=3, poly_n=5,
+              poly_sigma=1.2, flags=0, box_mode=BOX_RUNNING, capture=False):
+    """CPU oracle for cv2.calcOpticalFlowFarneback(prev, next, None, ...) -> float32[H,W,2].
+
+    With capture=True also returns a Capture of per-level intermediates (index = level k)."""
+    prev = np.ascontiguousarray(prev, np.uint8)
+    next = np.ascontiguousarray(next, np.uint8)
+    assert prev.ndim == 2 and prev.shape == next.shape
+    H, W = prev.shape
+    p = _params(pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags)
+    flow = np.empty((H, W, 2), np.float32)
+    cap_struct = None
+    cap = None
+    if capture:
+        nl = crop_levels(W, H, pyr_scale, levels) + 1
+        geo = [level_geom(W, H, pyr_scale, k) for k in range(nl)]
+        mk = lambda ch: [np.zeros((g[1], g[0]) + ((ch,) if ch > 1 else ()), np.float32) for g in geo]
+        cap = Capture(mk(1), mk(1), mk(5), mk(5), mk(5), mk(2), mk(2))
+        cap_struct = OfoCapture()
+        keep = []
+        for name in ("I0", "I1", "R0", "R1", "M_first", "flow_init", "flow_out"):
+            arr = (C.POINTER(C.c_float) * nl)(*[_fp(a) for a in getattr(cap, name)])
+            keep.append(arr)
+            setattr(cap_struct, name, C.cast(arr, C.POINTER(C.POINTER(C.c_float))))
+    rc = lib().ofo_farneback_ex(_u8p(prev), _u8p(next), W, H, W, C.byref(p), box_mode, _fp(flow),
+                                C.byref(cap_struct) if capture else None)
+    if rc != 0:
+        raise ValueError(f"oracle farneback rejected arguments (rc={rc})")
+    return (flow, cap) if capture else flow
+
+
+def farneback_batch(frames, pairs_mode=0, nthreads=1, box_mode=BOX_RUNNING, **kw):
+    """frames u8[n_frames,H,W] -> flow float32[n_pairs,H,W,2]; OpenMP across pairs if nthreads != 1."""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    n, H, W = frames.shape
+    n_pairs = n - 1 if pairs_mode else n // 2
+    p = _params(**kw)
+    flow = np.empty((n_pairs, H, W, 2), np.float32)
+    rc = lib(omp=(nthreads != 1)).ofo_farneback_batch(_u8p(frames), n_pairs, pairs_mode, W, H,
+                                                       C.byref(p), box_mode, _fp(flow), nthreads)
+    if rc != 0:
+        raise ValueError(f"oracle farneback_batch failed (rc={rc})")
+    return flow
+
+
+def omp_max_threads() -> int:
+    return lib(omp=True).ofo_max_threads()
+
+
+# --------------------------------------------------------------------------- filter: C twin
+def grid_points_c(width, height, step=30):
+    P = lib().ofo_grid_points(width, height, step, None)
+    pts = np.empty((P, 2), np.float32)
+    lib().ofo_grid_points(width, height, step, _fp(pts))
+    return pts
+
+
+def vector_filter_c(vec, pts, width, height):
+    vec = np.ascontiguousarray(vec, np.float32)
+    pts = np.ascontiguousarray(pts, np.float32)
+    P = len(pts)
+    mask = np.empty(P, np.uint8)
+    mod = np.empty(P, np.float32)
+    iflow = np.empty((P, 2), np.int32)
+    v = np.empty(P, np.uint8)
+    thr = np.empty(2, np.float64)
+    lib().ofo_vector_filter(_fp(vec), _fp(pts), P, width, height, _u8p(mask), _fp(mod),
+                            iflow.ctypes.data_as(C.POINTER(C.c_int32)), _u8p(v),
+                            thr.ctypes.data_as(C.POINTER(C.c_double)))
+    return mask.astype(bool), mod, iflow, v, thr
+
+
+# --------------------------------------------------------------------------- filter: the reference's NumPy
+def grid_points_numpy(width, height, step=30):
+    """pathfinder_viewer.py:255-267, re-typed."""
+    if width // step % 2 == 1:
+        indent_w = width % step / 2
+    else:
+        indent_w = (width % step + step) / 2
+    if height // step % 2 == 1:
+        indent_h = height % step / 2
+    else:
+        indent_h = (height % step + step) / 2
+    points_grid = np.mgrid[indent_w:width:step, indent_h:height:step].astype(int)
+    points = []
+    for x, y in zip(points_grid[0].flatten(), points_grid[1].flatten()):
+        points.append([x, y])
+    return np.array(points).astype(np.float32).reshape(-1, 2)
+
+
+def vector_filter_numpy(flow_, points_, width, height):
+    """pathfinder_viewer.py:159-176, re-typed (flow_ = next_pts - points_ is the input here).
+
+    Returns mask bool[P], modulus float32[P], int flow int32[P,2] for ALL points
+    (reference keeps [mask]), int points int32[P,2]."""
+    half_width = int(width / 2)
+    half_height = int(height / 2)
+    fx, fy = flow_[:, 0], flow_[:, 1]
+    x, y = points_[:, 0], points_[:, 1]
+    ang = np.arctan2(fy, fx)
+    modulus = np.sqrt(fx * fx + fy * fy)
+    modulus_middle = np.sqrt((half_width - x) ** 2 + (half_height - y) ** 2)
+    modulus = modulus / (5 + np.sqrt(modulus_middle)) * 30
+    fx = modulus * np.cos(ang)
+    fy = modulus * np.sin(ang)
+    next_pts = np.vstack([x + fx, y + fy]).T
+    next_pts = np.int32(next_pts + 0.5)
+    ipoints = np.int32(points_ + 0.5)
+    mask = (np.median(modulus) * 1.0 < modulus) & (modulus < np.percentile(modulus, 99))
+    return mask, modulus, next_pts - ipoints, ipoints
+
+
+def lamp_values_numpy(iflow_kept):
+    """pathfinder_viewer.py:204-217: V channel written per kept point (uint8 store truncates)."""
+    fx, fy = iflow_kept[:, 0], iflow_kept[:, 1]
+    modulus = np.sqrt(fx * fx + fy * fy)
+    out = np.zeros(len(iflow_kept), np.uint8)
+    for i, m in enumerate(modulus):
+        out[i] = np.minimum(50 + m * 2, 255)
+    return out
+
+
+def danger_map_numpy(flow_hw2, width, height, step=30):
+    """Dense adaptation: sample flow[y,x] at the grid (DenseOF.py:44-45), then filter.
+
+    Returns (mask u8[P], v u8[P]) with v = 0 at rejected points."""
+    pts = grid_points_numpy(width, height, step)
+    xi = pts[:, 0].astype(np.int64)
+    yi = pts[:, 1].astype(np.int64)
+    vec = np.ascontiguousarray(flow_hw2[yi, xi, :], np.float32)
+    mask, _, iflow, _ = vector_filter_numpy(vec, pts, width, height)
+    v = np.zeros(len(pts), np.uint8)
+    if mask.any():
+        v[mask] = lamp_values_numpy(iflow[mask])
+    return mask.astype(np.uint8), v

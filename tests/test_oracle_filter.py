@@ -1,0 +1,69 @@
+"""The C twin of the reference's NumPy grid / vector filter / danger brightness
+(oracle/filter_oracle.c) against the reference's own lines run by the real NumPy
+(oracle/oracle.py: pathfinder_viewer.py:159-176, 204-217, 252-267 re-typed)."""
+import numpy as np
+import pytest
+
+
+@pytest.mark.parametrize("w,h,step,P", [(1920, 1080, 30, 2304), (640, 480, 30, 352), (3840, 2160, 30, 9216),
+                                        (1920, 1080, 14, None), (1000, 700, 30, None), (641, 479, 25, None),
+                                        (97, 211, 30, None)])
+def test_grid_points(oracle, w, h, step, P):
+    ref = oracle.grid_points_numpy(w, h, step)
+    got = oracle.grid_points_c(w, h, step)
+    if P is not None:
+        assert len(ref) == P
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_grid_1080p_layout(oracle):
+    pts = oracle.grid_points_numpy(1920, 1080, 30)
+    assert pts.dtype == np.float32
+    assert tuple(pts[0]) == (15, 15) and tuple(pts[1]) == (15, 45) and tuple(pts[36]) == (45, 15)
+    assert tuple(pts[-1]) == (1905, 1065)
+
+
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("w,h", [(1920, 1080), (640, 480), (1000, 700)])
+def test_vector_filter_mask_bit_exact(oracle, seed, w, h):
+    rng = np.random.default_rng(seed)
+    pts = oracle.grid_points_numpy(w, h, 30)
+    scale = [0.01, 0.5, 3, 20][seed % 4]
+    vec = (rng.standard_normal((len(pts), 2)) * scale).astype(np.float32)
+    if seed == 5:
+        vec[::7] = 0            # exact zeros and ties
+        n = min(len(vec[1::7]), len(vec[2::7]))
+        vec[1::7][:n] = vec[2::7][:n]
+    mask, mod, iflow, _ = oracle.vector_filter_numpy(vec, pts, w, h)
+    cm, cmod, ciflow, cv, thr = oracle.vector_filter_c(vec, pts, w, h)
+    np.testing.assert_array_equal(cmod, mod)
+    assert thr[0] == float(np.median(mod) * 1.0)
+    assert thr[1] == float(np.percentile(mod, 99))
+    np.testing.assert_array_equal(cm, mask)
+    # integer flow passes through atan2f/cosf/sinf: library-specific last ulp, then truncation
+    assert (ciflow != iflow).any(axis=1).mean() <= 0.002
+    same = (ciflow == iflow).all(axis=1) & mask
+    v_ref = np.zeros(len(pts), np.uint8)
+    v_ref[mask] = oracle.lamp_values_numpy(iflow[mask])
+    np.testing.assert_array_equal(cv[same], v_ref[same])
+    assert np.all(cv[~mask] == 0)
+
+
+def test_percentile_small_sizes(oracle):
+    rng = np.random.default_rng(3)
+    for P in (2, 3, 5, 16, 101, 352):
+        pts = (rng.uniform(0, 300, (P, 2))).astype(np.float32)
+        vec = rng.standard_normal((P, 2)).astype(np.float32)
+        mask, mod, _, _ = oracle.vector_filter_numpy(vec, pts, 640, 480)
+        cm, cmod, _, _, thr = oracle.vector_filter_c(vec, pts, 640, 480)
+        assert thr[1] == float(np.percentile(mod, 99)) and thr[0] == float(np.median(mod))
+        np.testing.assert_array_equal(cm, mask)
+
+
+def test_danger_map_dense_adaptation(oracle):
+    rng = np.random.default_rng(4)
+    flow = rng.standard_normal((480, 640, 2)).astype(np.float32) * 4
+    mask, v = oracle.danger_map_numpy(flow, 640, 480)
+    assert mask.shape == (352,) and v.shape == (352,) and mask.dtype == np.uint8
+    assert 0 < mask.sum() < 352 // 2 + 1
+    assert np.all(v[mask == 0] == 0) and np.all(v[mask == 1] >= 50)
