@@ -1,0 +1,53 @@
+"""Builds libofarn.so (HIP kernels + C-ABI) in-tree with hipcc for gfx950.
+
+    python -m hackathonopticalflow_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off keeps every rounding of the arithmetic
+contract (no FMA contraction), which is what makes the device results comparable bit for bit
+with the CPU oracle.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "libofarn.so")
+SOURCES = ["kernels_generic.hip", "ofarn_api.hip"]
+HEADERS = [os.path.join(CSRC, "ofarn_internal.h"), os.path.join(ROOT, "include", "ofarn.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + HEADERS + [os.path.abspath(__file__)]):
+            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,486 @@
+// kernels_generic.hip -- parameter-generic HIP kernels for every stage of the Farneback pipeline.
+//
+// These kernels accept any (winsize, poly_n, pyr_scale, frame size).  They are the always-correct
+// path; kernels_fast.hip holds the specialisations the default parameter set dispatches to.
+//
+// Arithmetic contract: every kernel performs, per output element, the same IEEE-754 operations in
+// the same order as oracle/farneback_oracle.c (box order OFO_BOX_DIRECT), so results can be
+// compared bit for bit.  The library is built with -ffp-contract=off: no FMA contraction.
+//
+// Which OpenCV function each kernel stands for is given per kernel.
+#include "ofarn_internal.h"
+
+namespace ofarn {
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---------------------------------------------------------------------------------------------
+// Stage A, pass 1.  convertTo(CV_32F) + the ROW pass of GaussianBlur (BORDER_REFLECT_101),
+// evaluated only at the two source columns (sx, sx+1) each level column will interpolate between.
+//   s = k[0]*S[0]; s += k[t]*S[t]   (t = 1..ksize-1, left to right)
+// One thread per (y, dx); tmp[f][y][dx] = (value at sx, value at min(sx+1, W-1)).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_level_hpass(const uint8_t *__restrict__ frames,
+                                                      size_t frame_stride, int W, int H,
+                                                      const float *__restrict__ kern, int ksize,
+                                                      const int *__restrict__ xofs, int dw,
+                                                      float2 *__restrict__ tmp)
+{
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (dx >= dw) return;
+    const uint8_t *row = frames + (size_t)blockIdx.z * frame_stride + (size_t)y * W;
+    const int r = ksize >> 1;
+    const int sx = xofs[dx];
+    const int sx1 = sx + 1 < W ? sx + 1 : W - 1;
+    float s0, s1;
+    {
+        const float f = kern[0];
+        s0 = f * (float)row[reflect101(sx - r, W)];
+        s1 = f * (float)row[reflect101(sx1 - r, W)];
+    }
+    for (int t = 1; t < ksize; t++) {
+        const float f = kern[t];
+        s0 = s0 + f * (float)row[reflect101(sx - r + t, W)];
+        s1 = s1 + f * (float)row[reflect101(sx1 - r + t, W)];
+    }
+    tmp[((size_t)blockIdx.z * H + y) * dw + dx] = make_float2(s0, s1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage A, pass 2.  The COLUMN pass of GaussianBlur at source rows (sy, sy+1), then
+// resize(INTER_LINEAR): horizontal lerp first, vertical lerp second (resize.cpp HResize/VResize).
+//   column: s = k[r]*S[0]; s += k[r+t]*(S[+t] + S[-t])   (t = 1..r)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_level_vpass(const float2 *__restrict__ tmp, int H, int dw,
+                                                      int dh, const float *__restrict__ kern,
+                                                      int ksize, const float *__restrict__ xa,
+                                                      const int *__restrict__ yofs,
+                                                      const float *__restrict__ ya,
+                                                      float *__restrict__ I)
+{
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int dy = blockIdx.y;
+    if (dx >= dw) return;
+    const float2 *t = tmp + (size_t)blockIdx.z * H * dw + dx;
+    const int r = ksize >> 1;
+    const int sy = yofs[dy];
+    const int sy1 = sy + 1 < H ? sy + 1 : H - 1;
+    const float f0 = kern[r];
+    float2 c0 = t[(size_t)sy * dw], c1 = t[(size_t)sy1 * dw];
+    float b00 = f0 * c0.x, b01 = f0 * c0.y, b10 = f0 * c1.x, b11 = f0 * c1.y;
+    for (int k = 1; k <= r; k++) {
+        const float f = kern[r + k];
+        float2 p = t[(size_t)reflect101(sy + k, H) * dw], m = t[(size_t)reflect101(sy - k, H) * dw];
+        b00 = b00 + f * (p.x + m.x);
+        b01 = b01 + f * (p.y + m.y);
+        p = t[(size_t)reflect101(sy1 + k, H) * dw];
+        m = t[(size_t)reflect101(sy1 - k, H) * dw];
+        b10 = b10 + f * (p.x + m.x);
+        b11 = b11 + f * (p.y + m.y);
+    }
+    const float a1 = xa[dx], a0 = 1.f - a1;
+    const float row0 = b00 * a0 + b01 * a1;
+    const float row1 = b10 * a0 + b11 * a1;
+    const float w1 = ya[dy], w0 = 1.f - w1;
+    I[((size_t)blockIdx.z * dh + dy) * dw + dx] = row0 * w0 + row1 * w1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage B.  FarnebackPolyExp: (2n+1)-tap separable quadratic fit, replicate borders.
+// One 64x16 output tile per block; the level-image tile with an n-pixel halo is staged in LDS,
+// the float32 vertical pass writes the (r0, r1, r2) line buffers to LDS, the horizontal pass
+// accumulates in double exactly as optflowgf.cpp does (products of b2,b3,b5,b6 are float).
+// ---------------------------------------------------------------------------------------------
+constexpr int PE_TW = 64, PE_TH = 16;
+
+__global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, float *__restrict__ R,
+                                                  int w, int h, PolyCoef c)
+{
+    extern __shared__ float smem[];
+    const int n = c.n;
+    const int IW = PE_TW + 2 * n, IH = PE_TH + 2 * n;
+    float *sI = smem;                 // [IH][IW]
+    float *sR0 = sI + IH * IW;        // [PE_TH][IW]
+    float *sR1 = sR0 + PE_TH * IW;
+    float *sR2 = sR1 + PE_TH * IW;
+    const int x0 = blockIdx.x * PE_TW, y0 = blockIdx.y * PE_TH;
+    const size_t npx = (size_t)w * h;
+    const float *img = I + (size_t)blockIdx.z * npx;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < IH * IW; i += 256) {
+        const int ly = i / IW, lx = i - ly * IW;
+        const int gx = clampi(x0 - n + lx, 0, w - 1), gy = clampi(y0 - n + ly, 0, h - 1);
+        sI[i] = img[(size_t)gy * w + gx];
+    }
+    __syncthreads();
+    for (int i = tid; i < PE_TH * IW; i += 256) {
+        const int ly = i / IW, lx = i - ly * IW;
+        const float *col = sI + (ly + n) * IW + lx;
+        float r0 = col[0] * c.g[0], r1 = 0.f, r2 = 0.f;
+        for (int k = 1; k <= n; k++) {
+            const float a = col[-k * IW], b = col[k * IW];
+            const float p = a + b;
+            r0 = r0 + c.g[k] * p;
+            r1 = r1 + c.xg[k] * (b - a);
+            r2 = r2 + c.xxg[k] * p;
+        }
+        sR0[i] = r0; sR1[i] = r1; sR2[i] = r2;
+    }
+    __syncthreads();
+    float *out = R + (size_t)blockIdx.z * 5 * npx;
+    for (int i = tid; i < PE_TH * PE_TW; i += 256) {
+        const int ly = i / PE_TW, ox = i - ly * PE_TW;
+        const int gx = x0 + ox, gy = y0 + ly;
+        if (gx >= w || gy >= h) continue;
+        const float *p0 = sR0 + ly * IW + ox + n, *p1 = sR1 + ly * IW + ox + n, *p2 = sR2 + ly * IW + ox + n;
+        const float g0 = c.g[0];
+        double b1 = p0[0] * g0, b2 = 0, b3 = p1[0] * g0, b4 = 0, b5 = p2[0] * g0, b6 = 0;
+        for (int k = 1; k <= n; k++) {
+            const float gk = c.g[k], xgk = c.xg[k], xxgk = c.xxg[k];
+            const double tg = p0[k] + p0[-k];
+            b1 += tg * gk;
+            b4 += tg * xxgk;
+            b2 += (p0[k] - p0[-k]) * xgk;
+            b3 += (p1[k] + p1[-k]) * gk;
+            b6 += (p1[k] - p1[-k]) * xgk;
+            b5 += (p2[k] + p2[-k]) * gk;
+        }
+        const size_t o = (size_t)gy * w + gx;
+        out[o] = (float)(b3 * c.ig11);
+        out[npx + o] = (float)(b2 * c.ig11);
+        out[2 * npx + o] = (float)(b1 * c.ig03 + b5 * c.ig33);
+        out[3 * npx + o] = (float)(b1 * c.ig03 + b4 * c.ig33);
+        out[4 * npx + o] = (float)(b6 * c.ig55);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage E.  resize(prevFlow, INTER_LINEAR) then flow *= 1/pyr_scale (2-channel float).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flow_upsample(const float2 *__restrict__ src, int sw, int sh,
+                                                        float2 *__restrict__ dst, int dw, int dh,
+                                                        const int *__restrict__ xofs,
+                                                        const float *__restrict__ xa,
+                                                        const int *__restrict__ yofs,
+                                                        const float *__restrict__ ya, float mul)
+{
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int dy = blockIdx.y;
+    if (dx >= dw) return;
+    const float2 *s = src + (size_t)blockIdx.z * sw * sh;
+    const int sx = xofs[dx], sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
+    const int sy = yofs[dy], sy1 = sy + 1 < sh ? sy + 1 : sh - 1;
+    const float a1 = xa[dx], a0 = 1.f - a1, b1 = ya[dy], b0 = 1.f - b1;
+    const float2 p00 = s[(size_t)sy * sw + sx], p01 = s[(size_t)sy * sw + sx1];
+    const float2 p10 = s[(size_t)sy1 * sw + sx], p11 = s[(size_t)sy1 * sw + sx1];
+    const float r0x = p00.x * a0 + p01.x * a1, r0y = p00.y * a0 + p01.y * a1;
+    const float r1x = p10.x * a0 + p11.x * a1, r1y = p10.y * a0 + p11.y * a1;
+    float2 o;
+    o.x = (r0x * b0 + r1x * b1) * mul;
+    o.y = (r0y * b0 + r1y * b1) * mul;
+    dst[((size_t)blockIdx.z * dh + dy) * dw + dx] = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage C.  FarnebackUpdateMatrices: bilinear gather of R1 at (x+dx, y+dy), combine with R0,
+// 5-pixel border damping, form G11, G12, G22, h1, h2.  All float32.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void update_matrices_px(const float *__restrict__ R0, const float *__restrict__ R1,
+                                                    size_t npx, int w, int h, int x, int y, float dx,
+                                                    float dy, float out[5])
+{
+    float fx = (float)x + dx, fy = (float)y + dy;
+    const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    fx -= (float)x1; fy -= (float)y1;
+    const size_t o = (size_t)y * w + x;
+    float r2, r3, r4, r5, r6;
+    if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
+        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        const size_t q = (size_t)y1 * w + x1;
+        const float *p = R1 + q;
+        r2 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += npx;
+        r3 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += npx;
+        r4 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += npx;
+        r5 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += npx;
+        r6 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1];
+        r4 = (R0[2 * npx + o] + r4) * 0.5f;
+        r5 = (R0[3 * npx + o] + r5) * 0.5f;
+        r6 = (R0[4 * npx + o] + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = R0[2 * npx + o];
+        r5 = R0[3 * npx + o];
+        r6 = R0[4 * npx + o] * 0.5f;
+    }
+    r2 = (R0[o] - r2) * 0.5f;
+    r3 = (R0[npx + o] - r3) * 0.5f;
+    r2 = r2 + (r4 * dy + r6 * dx);
+    r3 = r3 + (r6 * dy + r5 * dx);
+    if ((unsigned)(x - kBorder) >= (unsigned)(w - kBorder * 2) ||
+        (unsigned)(y - kBorder) >= (unsigned)(h - kBorder * 2)) {
+        const float tab[kBorder] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+        const float scale = (x < kBorder ? tab[x] : 1.f) * (x >= w - kBorder ? tab[w - x - 1] : 1.f) *
+                            (y < kBorder ? tab[y] : 1.f) * (y >= h - kBorder ? tab[h - y - 1] : 1.f);
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    }
+    out[0] = r4 * r4 + r6 * r6;
+    out[1] = (r4 + r5) * r6;
+    out[2] = r5 * r5 + r6 * r6;
+    out[3] = r4 * r2 + r6 * r3;
+    out[4] = r6 * r2 + r5 * r3;
+}
+
+__global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict__ R, int fstep,
+                                                          const float2 *__restrict__ flow,
+                                                          float *__restrict__ M, int w, int h)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    const size_t npx = (size_t)w * h;
+    const size_t p = blockIdx.z;
+    const float *R0 = R + p * fstep * 5 * npx;
+    const float *R1 = R0 + 5 * npx;
+    const float2 d = flow[p * npx + (size_t)y * w + x];
+    float m[5];
+    update_matrices_px(R0, R1, npx, w, h, x, y, d.x, d.y, m);
+    float *out = M + p * 5 * npx + (size_t)y * w + x;
+#pragma unroll
+    for (int c = 0; c < 5; c++) out[c * npx] = m[c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage D.  FarnebackUpdateFlow_Blur: (2m+1)x(2m+1) box sum with replicate borders, scaled by
+// 1/winsize^2, then the regularised 2x2 solve.  Sums in double, in the fixed order
+//   column: sum_{j=-m..m} (double)M[clamp(y+j)][x],  window: sum_{i=-m..m} colsum[clamp(x+i)]
+// (oracle OFO_BOX_DIRECT).  One 64x16 tile per block, one channel at a time through LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int BS_TW = 64, BS_TH = 16;
+
+__global__ __launch_bounds__(256) void k_blur_solve(const float *__restrict__ M, float2 *__restrict__ flow,
+                                                     int w, int h, int m, double scale)
+{
+    extern __shared__ double smem_d[];
+    const int IW = BS_TW + 2 * m, IH = BS_TH + 2 * m;
+    double *sV = smem_d;                                   // [BS_TH][IW] column sums
+    float *sM = reinterpret_cast<float *>(sV + BS_TH * IW);  // [IH][IW]
+    const int x0 = blockIdx.x * BS_TW, y0 = blockIdx.y * BS_TH;
+    const size_t npx = (size_t)w * h;
+    const int tid = threadIdx.x;
+    const int ox = tid & 63, oy = tid >> 6;   // thread handles rows oy, oy+4, oy+8, oy+12
+    double acc[4][5];
+
+    for (int c = 0; c < 5; c++) {
+        const float *src = M + ((size_t)blockIdx.z * 5 + c) * npx;
+        for (int i = tid; i < IH * IW; i += 256) {
+            const int ly = i / IW, lx = i - ly * IW;
+            const int gx = clampi(x0 - m + lx, 0, w - 1), gy = clampi(y0 - m + ly, 0, h - 1);
+            sM[i] = src[(size_t)gy * w + gx];
+        }
+        __syncthreads();
+        for (int i = tid; i < BS_TH * IW; i += 256) {
+            const int ly = i / IW, lx = i - ly * IW;
+            const float *col = sM + ly * IW + lx;
+            double s = (double)col[0];
+            for (int j = 1; j <= 2 * m; j++) s += (double)col[j * IW];
+            sV[i] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const double *rowv = sV + (oy + 4 * q) * IW + ox;
+            double s = rowv[0];
+            for (int i = 1; i <= 2 * m; i++) s += rowv[i];
+            acc[q][c] = s;
+        }
+        __syncthreads();
+    }
+    const int gx = x0 + ox;
+    if (gx >= w) return;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int gy = y0 + oy + 4 * q;
+        if (gy >= h) continue;
+        const double g11 = acc[q][0] * scale, g12 = acc[q][1] * scale, g22 = acc[q][2] * scale;
+        const double h1 = acc[q][3] * scale, h2 = acc[q][4] * scale;
+        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+        float2 o;
+        o.x = (float)((g11 * h2 - g12 * h1) * idet);
+        o.y = (float)((g22 * h1 - g12 * h2) * idet);
+        flow[(size_t)blockIdx.z * npx + (size_t)gy * w + gx] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage F.  Sample flow[y][x] at the measurement grid (DenseOF.py:44-45), the vector filter of
+// pathfinder_viewer.py:159-176 and the V value of pathfinder_viewer.py:204-217.
+// One block per pair.  The equalised moduli are bitonic-sorted in LDS to read the order
+// statistics np.median / np.percentile(…, 99) need; all threshold arithmetic is float32, in
+// NumPy's order (see oracle/filter_oracle.c).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+__global__ __launch_bounds__(1024) void k_grid_filter(const float2 *__restrict__ flow, int w, int h,
+                                                       const int2 *__restrict__ pts, int P, int P2,
+                                                       uint8_t *__restrict__ mask, uint8_t *__restrict__ v)
+{
+    extern __shared__ float smem[];
+    float *srt = smem;          // [P2]
+    __shared__ float s_thr[2];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const float2 *f = flow + (size_t)blockIdx.x * w * h;
+    const float hw = (float)(w / 2), hh = (float)(h / 2);
+
+    for (int i = tid; i < P2; i += nt) {
+        float mval = __builtin_inff();
+        if (i < P) {
+            const int2 p = pts[i];
+            const float2 d = f[(size_t)p.y * w + p.x];
+            const float mod = __fsqrt_rn(d.x * d.x + d.y * d.y);
+            const float ddx = hw - (float)p.x, ddy = hh - (float)p.y;
+            const float mm = __fsqrt_rn(ddx * ddx + ddy * ddy);
+            mval = __fdiv_rn(mod, 5.0f + __fsqrt_rn(mm)) * 30.0f;
+        }
+        srt[i] = mval;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P2; i += nt) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const float a = srt[i], b = srt[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { srt[i] = b; srt[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        float med;
+        if (P & 1) med = srt[P / 2];
+        else med = (srt[P / 2 - 1] + srt[P / 2]) / 2.0f;
+        med = med * 1.0f;
+        const float quant = 99.0f / 100.0f;
+        const float vi = (float)(P - 1) * quant;
+        const float prevf = floorf(vi);
+        int pi = (int)prevf, ni = pi + 1;
+        if (vi >= (float)(P - 1)) { pi = P - 1; ni = P - 1; }
+        if (ni > P - 1) ni = P - 1;
+        const float t = vi - prevf;
+        const float a = srt[pi], b = srt[ni];
+        const float diff = b - a;
+        s_thr[0] = med;
+        s_thr[1] = (t >= 0.5f) ? b - diff * (1.0f - t) : a + diff * t;
+    }
+    __syncthreads();
+    const float med = s_thr[0], p99 = s_thr[1];
+    for (int i = tid; i < P; i += nt) {
+        const int2 p = pts[i];
+        const float2 d = f[(size_t)p.y * w + p.x];
+        const float x = (float)p.x, y = (float)p.y;
+        const float mod0 = __fsqrt_rn(d.x * d.x + d.y * d.y);
+        const float ddx = hw - x, ddy = hh - y;
+        const float mm = __fsqrt_rn(ddx * ddx + ddy * ddy);
+        const float mod = __fdiv_rn(mod0, 5.0f + __fsqrt_rn(mm)) * 30.0f;
+        const bool keep = (med < mod) && (mod < p99);
+        uint8_t val = 0;
+        if (keep) {
+            const float ang = atan2f(d.y, d.x);
+            const float gx = mod * cosf(ang), gy = mod * sinf(ang);
+            const int nx = (int)((x + gx) + 0.5f), ny = (int)((y + gy) + 0.5f);
+            const int px = (int)(x + 0.5f), py = (int)(y + 0.5f);
+            const int a = nx - px, b = ny - py;
+            double vv = 50.0 + sqrt((double)(a * a + b * b)) * 2.0;
+            if (vv > 255.0) vv = 255.0;
+            val = (uint8_t)vv;
+        }
+        mask[(size_t)blockIdx.x * P + i] = keep ? 1 : 0;
+        v[(size_t)blockIdx.x * P + i] = val;
+    }
+}
+
+// ------------------------------------------------------------------------------------ launchers
+static inline unsigned cdiv(int a, int b) { return (unsigned)((a + b - 1) / b); }
+
+void launch_level_hpass(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H,
+                        int nframes, const float *d_kern, int ksize, const int *d_xofs, int dw, float *tmp)
+{
+    dim3 grid(cdiv(dw, 256), H, nframes);
+    hipLaunchKernelGGL(k_level_hpass, grid, dim3(256), 0, s, frames, frame_stride, W, H, d_kern, ksize,
+                       d_xofs, dw, reinterpret_cast<float2 *>(tmp));
+}
+
+void launch_level_vpass(hipStream_t s, const float *tmp, int H, int dw, int dh, int nframes,
+                        const float *d_kern, int ksize, const float *d_xa, const int *d_yofs,
+                        const float *d_ya, float *I)
+{
+    dim3 grid(cdiv(dw, 256), dh, nframes);
+    hipLaunchKernelGGL(k_level_vpass, grid, dim3(256), 0, s, reinterpret_cast<const float2 *>(tmp), H, dw,
+                       dh, d_kern, ksize, d_xa, d_yofs, d_ya, I);
+}
+
+void launch_polyexp(hipStream_t s, const float *I, float *R, int w, int h, int nframes, const PolyCoef &c)
+{
+    const int n = c.n;
+    const int IW = PE_TW + 2 * n, IH = PE_TH + 2 * n;
+    const size_t lds = sizeof(float) * (size_t)(IH * IW + 3 * PE_TH * IW);
+    dim3 grid(cdiv(w, PE_TW), cdiv(h, PE_TH), nframes);
+    hipLaunchKernelGGL(k_polyexp, grid, dim3(256), lds, s, I, R, w, h, c);
+}
+
+void launch_flow_upsample(hipStream_t s, const float *src, int sw, int sh, float *dst, int dw, int dh,
+                          int npairs, const int *d_xofs, const float *d_xa, const int *d_yofs,
+                          const float *d_ya, float mul)
+{
+    dim3 grid(cdiv(dw, 256), dh, npairs);
+    hipLaunchKernelGGL(k_flow_upsample, grid, dim3(256), 0, s, reinterpret_cast<const float2 *>(src), sw, sh,
+                       reinterpret_cast<float2 *>(dst), dw, dh, d_xofs, d_xa, d_yofs, d_ya, mul);
+}
+
+void launch_update_matrices(hipStream_t s, const float *R, int fstep, const float *flow, float *M, int w,
+                            int h, int npairs)
+{
+    dim3 grid(cdiv(w, 256), h, npairs);
+    hipLaunchKernelGGL(k_update_matrices, grid, dim3(256), 0, s, R, fstep,
+                       reinterpret_cast<const float2 *>(flow), M, w, h);
+}
+
+void launch_blur_solve(hipStream_t s, const float *M, float *flow, int w, int h, int npairs, int winsize)
+{
+    const int m = winsize / 2;
+    const int IW = BS_TW + 2 * m, IH = BS_TH + 2 * m;
+    const size_t lds = sizeof(double) * (size_t)(BS_TH * IW) + sizeof(float) * (size_t)(IH * IW);
+    const double scale = 1. / ((double)winsize * winsize);
+    dim3 grid(cdiv(w, BS_TW), cdiv(h, BS_TH), npairs);
+    hipLaunchKernelGGL(k_blur_solve, grid, dim3(256), lds, s, M, reinterpret_cast<float2 *>(flow), w, h, m,
+                       scale);
+}
+
+int grid_filter_lds_bytes(int P)
+{
+    int p2 = 1;
+    while (p2 < P) p2 <<= 1;
+    return p2 * (int)sizeof(float);
+}
+
+void launch_grid_filter(hipStream_t s, const float *flow, int w, int h, int npairs, const int *d_pts, int P,
+                        uint8_t *mask, uint8_t *v)
+{
+    int p2 = 1;
+    while (p2 < P) p2 <<= 1;
+    hipLaunchKernelGGL(k_grid_filter, dim3(npairs), dim3(1024), (size_t)p2 * sizeof(float), s,
+                       reinterpret_cast<const float2 *>(flow), w, h, reinterpret_cast<const int2 *>(d_pts), P,
+                       p2, mask, v);
+}
+
+}  // namespace ofarn

@@ -1,0 +1,792 @@
+// ofarn_api.hip -- host side of libofarn.so: the C-ABI of include/ofarn.h.
+//
+// Owns the HBM workspace, the per-frame-size level plan (optflowgf.cpp calc(): level sizes,
+// Gaussian kernels, resize tables) and the per-level launch schedule
+//     A (level image) -> B (poly expansion) -> E (flow upsample) -> C, [D, C] x (I-1), D
+// for a wave of frame pairs at a time.  No oracle or CPU fallback exists on this path: if a HIP
+// call fails the entry point returns OFARN_E_HIP.
+#include "../../include/ofarn.h"
+#include "ofarn_internal.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace ofarn;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(OFARN_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+inline int cv_round(double v) { return (int)lrint(v); }   // cvRound: half to even
+inline int cv_floor(float v) { int i = (int)v; return i - (i > v); }
+
+// getGaussianKernel(n, sigma, CV_32F) -- smooth.dispatch.cpp
+std::vector<float> gaussian_kernel(int n, double sigma)
+{
+    std::vector<float> out(n);
+    if ((n & 1) && n <= 7 && sigma <= 0) {
+        static const float tab[4][7] = {{1.f},
+                                        {0.25f, 0.5f, 0.25f},
+                                        {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f},
+                                        {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f}};
+        for (int i = 0; i < n; i++) out[i] = tab[n >> 1][i];
+        return out;
+    }
+    const double sigmaX = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    const double scale2X = -0.5 / (sigmaX * sigmaX);
+    std::vector<double> v(n);
+    double sum = 0;
+    for (int i = 0; i < n; i++) {
+        const double x = i - (n - 1) * 0.5;
+        v[i] = std::exp(scale2X * x * x);
+        sum += v[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++) out[i] = (float)(v[i] * sum);
+    return out;
+}
+
+// resize(INTER_LINEAR) coordinate tables -- resize.cpp
+void resize_tables(int ssize, int dsize, std::vector<int> &ofs, std::vector<float> &alpha)
+{
+    const double inv_scale = (double)dsize / ssize;
+    const double scale = 1. / inv_scale;
+    ofs.resize(dsize);
+    alpha.resize(dsize);
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = cv_floor(f);
+        f -= s;
+        if (s < 0) { f = 0; s = 0; }
+        if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        ofs[d] = s;
+        alpha[d] = f;
+    }
+}
+
+// FarnebackPrepareGaussian -- optflowgf.cpp
+bool poly_prepare(int n, double sigma, PolyCoef &c)
+{
+    if (n < 1 || n > kMaxPolyN) return false;
+    if (sigma < FLT_EPSILON) sigma = n * 0.3;
+    std::vector<float> gb(2 * n + 1), xgb(2 * n + 1), xxgb(2 * n + 1);
+    float *g = gb.data() + n, *xg = xgb.data() + n, *xxg = xxgb.data() + n;
+    double s = 0.;
+    for (int x = -n; x <= n; x++) {
+        g[x] = (float)std::exp(-x * x / (2 * sigma * sigma));
+        s += g[x];
+    }
+    s = 1. / s;
+    for (int x = -n; x <= n; x++) {
+        g[x] = (float)(g[x] * s);
+        xg[x] = (float)(x * g[x]);
+        xxg[x] = (float)(x * x * g[x]);
+    }
+    double G[6][6];
+    memset(G, 0, sizeof(G));
+    for (int y = -n; y <= n; y++)
+        for (int x = -n; x <= n; x++) {
+            G[0][0] += g[y] * g[x];
+            G[1][1] += g[y] * g[x] * x * x;
+            G[3][3] += g[y] * g[x] * x * x * x * x;
+            G[5][5] += g[y] * g[x] * x * x * y * y;
+        }
+    G[2][2] = G[0][3] = G[0][4] = G[3][0] = G[4][0] = G[1][1];
+    G[4][4] = G[3][3];
+    G[3][4] = G[4][3] = G[5][5];
+    // 6x6 inverse, Gauss-Jordan with partial pivoting
+    double a[6][12];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) { a[i][j] = G[i][j]; a[i][j + 6] = (i == j); }
+    for (int col = 0; col < 6; col++) {
+        int p = col;
+        for (int r = col + 1; r < 6; r++) if (std::fabs(a[r][col]) > std::fabs(a[p][col])) p = r;
+        if (p != col) for (int j = 0; j < 12; j++) std::swap(a[col][j], a[p][j]);
+        const double d = 1. / a[col][col];
+        for (int j = 0; j < 12; j++) a[col][j] *= d;
+        for (int r = 0; r < 6; r++) if (r != col) {
+            const double f = a[r][col];
+            if (f != 0) for (int j = 0; j < 12; j++) a[r][j] -= f * a[col][j];
+        }
+    }
+    memset(&c, 0, sizeof(c));
+    c.n = n;
+    for (int k = 0; k <= n; k++) { c.g[k] = g[k]; c.xg[k] = xg[k]; c.xxg[k] = xxg[k]; }
+    c.ig11 = a[1][7]; c.ig03 = a[0][9]; c.ig33 = a[3][9]; c.ig55 = a[5][11];
+    return true;
+}
+
+struct Level {
+    int w = 0, h = 0, ksize = 0;
+    double sigma = 0;
+    // device tables
+    float *d_kern = nullptr;
+    int *d_xofs = nullptr, *d_yofs = nullptr;        // image resize W->w, H->h
+    float *d_xa = nullptr, *d_ya = nullptr;
+    int *d_fxofs = nullptr, *d_fyofs = nullptr;      // flow resize (k+1) -> k
+    float *d_fxa = nullptr, *d_fya = nullptr;
+};
+
+int axis_points(int size, int step, std::vector<int> *out)
+{
+    // pathfinder_viewer.py:255-262 + np.mgrid[indent:size:step].astype(int)
+    const double indent = ((size / step) % 2 == 1) ? (size % step) / 2.0 : ((size % step) + step) / 2.0;
+    int n = (int)std::ceil((size - indent) / (step * 1.0));
+    if (n < 0) n = 0;
+    if (out) {
+        out->resize(n);
+        for (int i = 0; i < n; i++) (*out)[i] = (int)(i * (double)step + indent);
+    }
+    return n;
+}
+
+int crop_levels(int W, int H, double pyr_scale, int levels)
+{
+    int k;
+    double scale = 1;
+    for (k = 0; k < levels; k++) {
+        scale *= pyr_scale;
+        if (W * scale < 32 || H * scale < 32) break;   // min_size = 32
+    }
+    return k;
+}
+
+void level_geom(int W, int H, double pyr_scale, int k, int &w, int &h, double &sigma, int &ksize)
+{
+    double scale = 1;
+    for (int i = 0; i < k; i++) scale *= pyr_scale;
+    sigma = (1. / scale - 1) * 0.5;
+    ksize = cv_round(sigma * 5) | 1;
+    if (ksize < 3) ksize = 3;
+    w = cv_round(W * scale);
+    h = cv_round(H * scale);
+}
+
+int check_params(const ofarn_params *p)
+{
+    if (!p) return fail(OFARN_E_INVALID, "params is NULL");
+    if (!(p->pyr_scale < 1) || !(p->pyr_scale > 0))
+        return fail(OFARN_E_INVALID, "pyr_scale must be in (0, 1) (cv2: CV_Assert(pyrScale_ < 1)), got %g", p->pyr_scale);
+    if (p->levels < 0) return fail(OFARN_E_INVALID, "levels must be >= 0, got %d", p->levels);
+    if (p->winsize < 2) return fail(OFARN_E_INVALID, "winsize must be >= 2, got %d", p->winsize);
+    if (p->iterations < 0) return fail(OFARN_E_INVALID, "iterations must be >= 0, got %d", p->iterations);
+    if (p->poly_n < 1 || p->poly_n > kMaxPolyN)
+        return fail(OFARN_E_INVALID, "poly_n must be in [1, %d], got %d", kMaxPolyN, p->poly_n);
+    if (p->flags != 0)
+        return fail(OFARN_E_UNSUPPORTED, "flags=%d: OPTFLOW_USE_INITIAL_FLOW / OPTFLOW_FARNEBACK_GAUSSIAN are not built yet", p->flags);
+    if (p->grid_step < 1) return fail(OFARN_E_INVALID, "grid_step must be >= 1, got %d", p->grid_step);
+    return OFARN_OK;
+}
+
+}  // namespace
+
+struct ofarn_ctx {
+    ofarn_params prm{};
+    int device = 0;
+    int max_w = 0, max_h = 0, max_batch = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    PolyCoef poly{};
+    // plan (cached for one frame size)
+    int plan_w = 0, plan_h = 0;
+    std::vector<Level> lv;
+    int *d_pts = nullptr;
+    int P = 0;
+    std::vector<void *> plan_allocs;
+    // workspace
+    float *tmp = nullptr, *I = nullptr, *R = nullptr, *M = nullptr, *flowA = nullptr, *flowB = nullptr;
+    uint64_t ws_bytes = 0;
+    // host-API staging (lazy)
+    uint8_t *st_frames = nullptr;
+    float *st_flow = nullptr;
+    uint8_t *st_mask = nullptr, *st_v = nullptr;
+    size_t st_frames_cap = 0, st_flow_cap = 0, st_dm_cap = 0;
+    double last_ms = 0;
+    // per-kernel profiling (ofarn_profile_*): hipEvent pairs around each launch, on the launch stream
+    struct ProfRec { int stage, level; double units; hipEvent_t a, b; };
+    bool prof_on = false;
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> prof_free;
+    struct ProfAcc { int launches = 0; double ms = 0, units = 0; };
+    ProfAcc prof_acc[OFARN_STAGE_COUNT][32];
+};
+
+namespace {
+
+void free_plan(ofarn_ctx *c)
+{
+    for (void *p : c->plan_allocs) (void)hipFree(p);
+    c->plan_allocs.clear();
+    c->lv.clear();
+    c->d_pts = nullptr;
+    c->plan_w = c->plan_h = 0;
+    c->P = 0;
+}
+
+template <typename T>
+int upload(ofarn_ctx *c, const std::vector<T> &v, T **out)
+{
+    void *d = nullptr;
+    HIP_TRY(hipMalloc(&d, v.size() * sizeof(T) + 16));
+    c->plan_allocs.push_back(d);
+    HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<T *>(d);
+    return OFARN_OK;
+}
+
+int make_plan(ofarn_ctx *c, int w, int h)
+{
+    if (c->plan_w == w && c->plan_h == h) return OFARN_OK;
+    free_plan(c);
+    const int nlev = crop_levels(w, h, c->prm.pyr_scale, c->prm.levels);
+    c->lv.resize(nlev + 1);
+    for (int k = 0; k <= nlev; k++) {
+        Level &L = c->lv[k];
+        level_geom(w, h, c->prm.pyr_scale, k, L.w, L.h, L.sigma, L.ksize);
+        if (L.w < 1 || L.h < 1) return fail(OFARN_E_INVALID, "level %d is empty", k);
+        int rc;
+        if ((rc = upload(c, gaussian_kernel(L.ksize, L.sigma), &L.d_kern))) return rc;
+        std::vector<int> ofs;
+        std::vector<float> al;
+        resize_tables(w, L.w, ofs, al);
+        if ((rc = upload(c, ofs, &L.d_xofs)) || (rc = upload(c, al, &L.d_xa))) return rc;
+        resize_tables(h, L.h, ofs, al);
+        if ((rc = upload(c, ofs, &L.d_yofs)) || (rc = upload(c, al, &L.d_ya))) return rc;
+    }
+    for (int k = 0; k < nlev; k++) {
+        Level &L = c->lv[k];
+        const Level &S = c->lv[k + 1];
+        std::vector<int> ofs;
+        std::vector<float> al;
+        int rc;
+        resize_tables(S.w, L.w, ofs, al);
+        if ((rc = upload(c, ofs, &L.d_fxofs)) || (rc = upload(c, al, &L.d_fxa))) return rc;
+        resize_tables(S.h, L.h, ofs, al);
+        if ((rc = upload(c, ofs, &L.d_fyofs)) || (rc = upload(c, al, &L.d_fya))) return rc;
+    }
+    std::vector<int> xs, ys;
+    axis_points(w, c->prm.grid_step, &xs);
+    axis_points(h, c->prm.grid_step, &ys);
+    std::vector<int> pts;
+    for (int x : xs)
+        for (int y : ys) { pts.push_back(x); pts.push_back(y); }
+    c->P = (int)(pts.size() / 2);
+    if (c->P > 0) {
+        int rc;
+        if ((rc = upload(c, pts, &c->d_pts))) return rc;
+    }
+    c->plan_w = w;
+    c->plan_h = h;
+    return OFARN_OK;
+}
+
+hipEvent_t prof_event(ofarn_ctx *c)
+{
+    if (!c->prof_free.empty()) { hipEvent_t e = c->prof_free.back(); c->prof_free.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// Runs `launch` and, when profiling is on, brackets it with two events on the same stream.
+template <typename F>
+inline void timed(ofarn_ctx *c, hipStream_t s, int stage, int level, double units, F &&launch)
+{
+    if (!c->prof_on) { launch(); return; }
+    ofarn_ctx::ProfRec r{stage, level, units, prof_event(c), prof_event(c)};
+    (void)hipEventRecord(r.a, s);
+    launch();
+    (void)hipEventRecord(r.b, s);
+    c->prof_pending.push_back(r);
+}
+
+// One wave: npairs <= max_batch pairs, frames already in HBM.
+int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, int pairs_mode, int w,
+             int h, float *d_flow, uint8_t *d_mask, uint8_t *d_v)
+{
+    const int fstep = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? 1 : 2;
+    const int nframes = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? npairs + 1 : 2 * npairs;
+    const size_t fsz = (size_t)w * h;
+    const int nlev = (int)c->lv.size() - 1;
+    float *prev = nullptr;
+    int pw = 0, ph = 0;
+    float *bufs[2] = {c->flowA, c->flowB};
+    int flip = 0;
+    for (int k = nlev; k >= 0; k--) {
+        const Level &L = c->lv[k];
+        float *flow = (k == 0 && d_flow) ? d_flow : bufs[flip];
+        flip ^= 1;
+        const size_t npx = (size_t)L.w * L.h;
+        const double upx = (double)npx * npairs, ufr = (double)npx * nframes;
+        if (!prev) HIP_TRY(hipMemsetAsync(flow, 0, npx * 2 * sizeof(float) * npairs, s));
+        else
+            timed(c, s, OFARN_STAGE_UPSAMPLE, k, upx, [&] {
+                launch_flow_upsample(s, prev, pw, ph, flow, L.w, L.h, npairs, L.d_fxofs, L.d_fxa, L.d_fyofs,
+                                     L.d_fya, (float)(1. / c->prm.pyr_scale));
+            });
+        timed(c, s, OFARN_STAGE_LEVEL_H, k, ufr, [&] {
+            launch_level_hpass(s, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, c->tmp);
+        });
+        timed(c, s, OFARN_STAGE_LEVEL_V, k, ufr, [&] {
+            launch_level_vpass(s, c->tmp, h, L.w, L.h, nframes, L.d_kern, L.ksize, L.d_xa, L.d_yofs, L.d_ya, c->I);
+        });
+        timed(c, s, OFARN_STAGE_POLYEXP, k, ufr, [&] { launch_polyexp(s, c->I, c->R, L.w, L.h, nframes, c->poly); });
+        timed(c, s, OFARN_STAGE_MATRICES, k, upx, [&] { launch_update_matrices(s, c->R, fstep, flow, c->M, L.w, L.h, npairs); });
+        for (int i = 0; i < c->prm.iterations; i++) {
+            timed(c, s, OFARN_STAGE_BLUR_SOLVE, k, upx, [&] { launch_blur_solve(s, c->M, flow, L.w, L.h, npairs, c->prm.winsize); });
+            if (i < c->prm.iterations - 1)
+                timed(c, s, OFARN_STAGE_MATRICES, k, upx, [&] { launch_update_matrices(s, c->R, fstep, flow, c->M, L.w, L.h, npairs); });
+        }
+        prev = flow; pw = L.w; ph = L.h;
+    }
+    if ((d_mask || d_v) && c->P > 0) {
+        if (!d_mask || !d_v) return fail(OFARN_E_INVALID, "danger mask and v must be given together");
+        timed(c, s, OFARN_STAGE_GRID_FILTER, 0, (double)c->P * npairs, [&] {
+            launch_grid_filter(s, prev, w, h, npairs, c->d_pts, c->P, d_mask, d_v);
+        });
+    }
+    HIP_TRY(hipGetLastError());
+    return OFARN_OK;
+}
+
+int check_size(ofarn_ctx *c, int w, int h)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    if (w < 1 || h < 1) return fail(OFARN_E_INVALID, "empty frame %dx%d", w, h);
+    if ((size_t)w * h > (size_t)c->max_w * c->max_h)
+        return fail(OFARN_E_SIZE, "frame %dx%d exceeds the context's %dx%d", w, h, c->max_w, c->max_h);
+    return OFARN_OK;
+}
+
+int ensure_staging(ofarn_ctx *c, size_t frames_bytes, size_t flow_bytes, size_t dm_bytes)
+{
+    if (frames_bytes > c->st_frames_cap) {
+        if (c->st_frames) (void)hipFree(c->st_frames);
+        c->st_frames = nullptr; c->st_frames_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c->st_frames, frames_bytes));
+        c->st_frames_cap = frames_bytes;
+    }
+    if (flow_bytes > c->st_flow_cap) {
+        if (c->st_flow) (void)hipFree(c->st_flow);
+        c->st_flow = nullptr; c->st_flow_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c->st_flow, flow_bytes));
+        c->st_flow_cap = flow_bytes;
+    }
+    if (dm_bytes > c->st_dm_cap) {
+        if (c->st_mask) (void)hipFree(c->st_mask);
+        if (c->st_v) (void)hipFree(c->st_v);
+        c->st_mask = c->st_v = nullptr; c->st_dm_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c->st_mask, dm_bytes));
+        HIP_TRY(hipMalloc((void **)&c->st_v, dm_bytes));
+        c->st_dm_cap = dm_bytes;
+    }
+    return OFARN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ofarn_default_params(ofarn_params *p)
+{
+    if (!p) return;
+    p->pyr_scale = 0.5; p->levels = 3; p->winsize = 15; p->iterations = 3;
+    p->poly_n = 5; p->poly_sigma = 1.2; p->flags = 0; p->grid_step = 30;
+}
+
+const char *ofarn_last_error(void) { return g_err.c_str(); }
+
+const char *ofarn_version(void) { return "ofarn 0.1.0 gfx950 (HIP, fp-contract=off)"; }
+
+int ofarn_create(const ofarn_params *params, int device, int max_w, int max_h, int max_batch, ofarn_ctx **out)
+{
+    if (!out) return fail(OFARN_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (max_w < 1 || max_h < 1 || max_batch < 1)
+        return fail(OFARN_E_INVALID, "max_w, max_h, max_batch must be >= 1 (got %d, %d, %d)", max_w, max_h, max_batch);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(OFARN_E_HIP, "no HIP device visible; libofarn has no CPU path");
+    if (device < 0 || device >= ndev) return fail(OFARN_E_INVALID, "device %d out of range [0, %d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    ofarn_ctx *c = new ofarn_ctx();
+    c->prm = *params;
+    c->device = device;
+    c->max_w = max_w; c->max_h = max_h; c->max_batch = max_batch;
+    if (!poly_prepare(params->poly_n, params->poly_sigma, c->poly)) {
+        delete c;
+        return fail(OFARN_E_INVALID, "poly_n out of range");
+    }
+    auto bail = [&](int code) { ofarn_destroy(c); return code; };
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
+        return bail(fail(OFARN_E_HIP, "stream/event creation failed"));
+    const size_t px = (size_t)max_w * max_h;
+    const size_t F = (size_t)2 * max_batch, Pn = (size_t)max_batch;
+    struct { float **p; size_t n; } req[] = {
+        {&c->tmp, F * px * 2}, {&c->I, F * px}, {&c->R, F * px * 5}, {&c->M, Pn * px * 5},
+        {&c->flowA, Pn * px * 2}, {&c->flowB, Pn * px * 2}};
+    for (auto &r : req) {
+        const size_t bytes = r.n * sizeof(float) + 256;
+        if (hipMalloc((void **)r.p, bytes) != hipSuccess)
+            return bail(fail(OFARN_E_NOMEM, "workspace of %zu bytes does not fit (max_batch=%d at %dx%d)", bytes, max_batch, max_w, max_h));
+        c->ws_bytes += bytes;
+    }
+    *out = c;
+    return OFARN_OK;
+}
+
+void ofarn_destroy(ofarn_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_plan(c);
+    for (float *p : {c->tmp, c->I, c->R, c->M, c->flowA, c->flowB, c->st_flow}) if (p) (void)hipFree(p);
+    for (uint8_t *p : {c->st_frames, c->st_mask, c->st_v}) if (p) (void)hipFree(p);
+    for (auto &r : c->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (hipEvent_t e : c->prof_free) (void)hipEventDestroy(e);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+double ofarn_last_device_ms(const ofarn_ctx *c) { return c ? c->last_ms : 0; }
+uint64_t ofarn_workspace_bytes(const ofarn_ctx *c) { return c ? c->ws_bytes : 0; }
+
+int ofarn_profile_enable(ofarn_ctx *c, int on)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    c->prof_on = on != 0;
+    return OFARN_OK;
+}
+
+int ofarn_profile_read(ofarn_ctx *c, int cap, int *stage, int *level, int *launches, double *ms, double *units)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    for (auto &r : c->prof_pending) {
+        HIP_TRY(hipEventSynchronize(r.b));
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+        if (r.level >= 0 && r.level < 32) {
+            auto &a = c->prof_acc[r.stage][r.level];
+            a.launches++; a.ms += t; a.units += r.units;
+        }
+        c->prof_free.push_back(r.a);
+        c->prof_free.push_back(r.b);
+    }
+    c->prof_pending.clear();
+    int n = 0;
+    for (int st = 0; st < OFARN_STAGE_COUNT; st++)
+        for (int lv = 0; lv < 32; lv++) {
+            auto &a = c->prof_acc[st][lv];
+            if (!a.launches) continue;
+            if (n < cap) {
+                if (stage) stage[n] = st;
+                if (level) level[n] = lv;
+                if (launches) launches[n] = a.launches;
+                if (ms) ms[n] = a.ms;
+                if (units) units[n] = a.units;
+            }
+            n++;
+            a = ofarn_ctx::ProfAcc();
+        }
+    return n;
+}
+
+int ofarn_level_plan(const ofarn_params *p, int w, int h, int cap, int *lw, int *lh, int *ksize, double *sigma)
+{
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (w < 1 || h < 1) return fail(OFARN_E_INVALID, "empty frame");
+    const int nlev = crop_levels(w, h, p->pyr_scale, p->levels);
+    for (int k = 0; k <= nlev && k < cap; k++) {
+        int a, b, ks;
+        double sg;
+        level_geom(w, h, p->pyr_scale, k, a, b, sg, ks);
+        if (lw) lw[k] = a;
+        if (lh) lh[k] = b;
+        if (ksize) ksize[k] = ks;
+        if (sigma) sigma[k] = sg;
+    }
+    return nlev + 1;
+}
+
+int ofarn_grid_points(int w, int h, int step, float *h_pts)
+{
+    if (w < 1 || h < 1 || step < 1) return fail(OFARN_E_INVALID, "bad grid arguments");
+    std::vector<int> xs, ys;
+    axis_points(w, step, &xs);
+    axis_points(h, step, &ys);
+    if (h_pts) {
+        size_t i = 0;
+        for (int x : xs)
+            for (int y : ys) { h_pts[i++] = (float)x; h_pts[i++] = (float)y; }
+    }
+    return (int)(xs.size() * ys.size());
+}
+
+int ofarn_calc_batch_device(ofarn_ctx *c, const uint8_t *d_frames, int n_frames, int w, int h, int pairs_mode,
+                            float *d_flow, uint8_t *d_mask, uint8_t *d_v, void *hip_stream)
+{
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    if (!d_frames) return fail(OFARN_E_INVALID, "frames is NULL");
+    if (pairs_mode != OFARN_PAIRS_INDEPENDENT && pairs_mode != OFARN_PAIRS_CONSECUTIVE)
+        return fail(OFARN_E_INVALID, "pairs_mode must be 0 or 1");
+    const int n_pairs = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? n_frames - 1 : n_frames / 2;
+    if (n_pairs < 0 || (pairs_mode == OFARN_PAIRS_INDEPENDENT && (n_frames & 1)))
+        return fail(OFARN_E_INVALID, "n_frames=%d does not form whole pairs in mode %d", n_frames, pairs_mode);
+    if (n_pairs == 0) return OFARN_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = make_plan(c, w, h))) return rc;
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    const size_t fsz = (size_t)w * h;
+    const int fstep = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? 1 : 2;
+    for (int p0 = 0; p0 < n_pairs; p0 += c->max_batch) {
+        const int np = n_pairs - p0 < c->max_batch ? n_pairs - p0 : c->max_batch;
+        rc = run_wave(c, s, d_frames + (size_t)p0 * fstep * fsz, np, pairs_mode, w, h,
+                      d_flow ? d_flow + (size_t)p0 * fsz * 2 : nullptr,
+                      d_mask ? d_mask + (size_t)p0 * c->P : nullptr, d_v ? d_v + (size_t)p0 * c->P : nullptr);
+        if (rc) return rc;
+    }
+    return OFARN_OK;
+}
+
+int ofarn_calc_batch(ofarn_ctx *c, const uint8_t *h_frames, int n_frames, int w, int h, int pairs_mode,
+                     float *h_flow, uint8_t *h_mask, uint8_t *h_v)
+{
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    if (!h_frames) return fail(OFARN_E_INVALID, "frames is NULL");
+    if (pairs_mode != OFARN_PAIRS_INDEPENDENT && pairs_mode != OFARN_PAIRS_CONSECUTIVE)
+        return fail(OFARN_E_INVALID, "pairs_mode must be 0 or 1");
+    const int n_pairs = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? n_frames - 1 : n_frames / 2;
+    if (n_pairs < 0 || (pairs_mode == OFARN_PAIRS_INDEPENDENT && (n_frames & 1)))
+        return fail(OFARN_E_INVALID, "n_frames=%d does not form whole pairs in mode %d", n_frames, pairs_mode);
+    if ((h_mask == nullptr) != (h_v == nullptr)) return fail(OFARN_E_INVALID, "danger mask and v must be given together");
+    if (n_pairs == 0) return OFARN_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = make_plan(c, w, h))) return rc;
+    const size_t fsz = (size_t)w * h;
+    const int fstep = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? 1 : 2;
+    const int wave = c->max_batch;
+    const size_t wave_frames = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? wave + 1 : 2 * (size_t)wave;
+    if ((rc = ensure_staging(c, wave_frames * fsz, (size_t)wave * fsz * 2 * sizeof(float),
+                             h_mask ? (size_t)wave * (c->P > 0 ? c->P : 1) : 0)))
+        return rc;
+    double ms_total = 0;
+    for (int p0 = 0; p0 < n_pairs; p0 += wave) {
+        const int np = n_pairs - p0 < wave ? n_pairs - p0 : wave;
+        const int nf = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? np + 1 : 2 * np;
+        HIP_TRY(hipMemcpyAsync(c->st_frames, h_frames + (size_t)p0 * fstep * fsz, (size_t)nf * fsz,
+                               hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        rc = run_wave(c, c->stream, c->st_frames, np, pairs_mode, w, h, c->st_flow, h_mask ? c->st_mask : nullptr,
+                      h_mask ? c->st_v : nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        if (h_flow)
+            HIP_TRY(hipMemcpyAsync(h_flow + (size_t)p0 * fsz * 2, c->st_flow, (size_t)np * fsz * 2 * sizeof(float),
+                                   hipMemcpyDeviceToHost, c->stream));
+        if (h_mask && c->P > 0) {
+            HIP_TRY(hipMemcpyAsync(h_mask + (size_t)p0 * c->P, c->st_mask, (size_t)np * c->P, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(h_v + (size_t)p0 * c->P, c->st_v, (size_t)np * c->P, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        ms_total += ms;
+    }
+    c->last_ms = ms_total;
+    return OFARN_OK;
+}
+
+int ofarn_calc(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next, int w, int h, int stride, float *h_flow)
+{
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    if (!h_prev || !h_next || !h_flow) return fail(OFARN_E_INVALID, "prev, next and flow must not be NULL");
+    if (stride < w) return fail(OFARN_E_INVALID, "stride %d < width %d", stride, w);
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = make_plan(c, w, h))) return rc;
+    const size_t fsz = (size_t)w * h;
+    if ((rc = ensure_staging(c, 2 * fsz, fsz * 2 * sizeof(float), 0))) return rc;
+    HIP_TRY(hipMemcpy2DAsync(c->st_frames, w, h_prev, stride, w, h, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpy2DAsync(c->st_frames + fsz, w, h_next, stride, w, h, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if ((rc = run_wave(c, c->stream, c->st_frames, 1, OFARN_PAIRS_INDEPENDENT, w, h, c->st_flow, nullptr, nullptr))) return rc;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipMemcpyAsync(h_flow, c->st_flow, fsz * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_ms = ms;
+    return OFARN_OK;
+}
+
+int ofarn_grid_filter_device(ofarn_ctx *c, const float *d_flow, int n, int w, int h, uint8_t *d_mask, uint8_t *d_v,
+                             void *hip_stream)
+{
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    if (!d_flow || !d_mask || !d_v) return fail(OFARN_E_INVALID, "flow, mask and v must not be NULL");
+    if (n < 0) return fail(OFARN_E_INVALID, "n < 0");
+    if (n == 0) return OFARN_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = make_plan(c, w, h))) return rc;
+    if (c->P == 0) return OFARN_OK;
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    launch_grid_filter(s, d_flow, w, h, n, c->d_pts, c->P, d_mask, d_v);
+    HIP_TRY(hipGetLastError());
+    return OFARN_OK;
+}
+
+int ofarn_grid_filter(ofarn_ctx *c, const float *h_flow, int n, int w, int h, uint8_t *h_mask, uint8_t *h_v)
+{
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    if (!h_flow || !h_mask || !h_v) return fail(OFARN_E_INVALID, "flow, mask and v must not be NULL");
+    if (n < 0) return fail(OFARN_E_INVALID, "n < 0");
+    if (n == 0) return OFARN_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = make_plan(c, w, h))) return rc;
+    if (c->P == 0) return OFARN_OK;
+    const size_t fsz = (size_t)w * h * 2 * sizeof(float);
+    if ((rc = ensure_staging(c, 0, fsz, (size_t)c->P))) return rc;
+    for (int i = 0; i < n; i++) {
+        HIP_TRY(hipMemcpyAsync(c->st_flow, h_flow + (size_t)i * w * h * 2, fsz, hipMemcpyHostToDevice, c->stream));
+        launch_grid_filter(c->stream, c->st_flow, w, h, 1, c->d_pts, c->P, c->st_mask, c->st_v);
+        HIP_TRY(hipMemcpyAsync(h_mask + (size_t)i * c->P, c->st_mask, c->P, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(h_v + (size_t)i * c->P, c->st_v, c->P, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return OFARN_OK;
+}
+
+// ------------------------------------------------------------------ single-stage entry points
+// Each uses the context workspace for one image; inputs/outputs are host arrays.
+
+int ofarn_stage_level_image(ofarn_ctx *c, const uint8_t *h_img, int w, int h, int k, float *h_out)
+{
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    if (!h_img || !h_out) return fail(OFARN_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = make_plan(c, w, h))) return rc;
+    if (k < 0 || k >= (int)c->lv.size()) return fail(OFARN_E_INVALID, "level %d out of range", k);
+    const Level &L = c->lv[k];
+    const size_t fsz = (size_t)w * h;
+    if ((rc = ensure_staging(c, fsz, 0, 0))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->st_frames, h_img, fsz, hipMemcpyHostToDevice, c->stream));
+    launch_level_hpass(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->tmp);
+    launch_level_vpass(c->stream, c->tmp, h, L.w, L.h, 1, L.d_kern, L.ksize, L.d_xa, L.d_yofs, L.d_ya, c->I);
+    HIP_TRY(hipMemcpyAsync(h_out, c->I, (size_t)L.w * L.h * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return OFARN_OK;
+}
+
+int ofarn_stage_polyexp(ofarn_ctx *c, const float *h_img, int w, int h, float *h_R)
+{
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    if (!h_img || !h_R) return fail(OFARN_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t npx = (size_t)w * h;
+    HIP_TRY(hipMemcpyAsync(c->I, h_img, npx * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    launch_polyexp(c->stream, c->I, c->R, w, h, 1, c->poly);
+    HIP_TRY(hipMemcpyAsync(h_R, c->R, npx * 5 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return OFARN_OK;
+}
+
+int ofarn_stage_update_matrices(ofarn_ctx *c, const float *h_R0, const float *h_R1, const float *h_flow, int w, int h,
+                                float *h_M)
+{
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    if (!h_R0 || !h_R1 || !h_flow || !h_M) return fail(OFARN_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t npx = (size_t)w * h;
+    HIP_TRY(hipMemcpyAsync(c->R, h_R0, npx * 5 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->R + npx * 5, h_R1, npx * 5 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->flowA, h_flow, npx * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    launch_update_matrices(c->stream, c->R, 2, c->flowA, c->M, w, h, 1);
+    HIP_TRY(hipMemcpyAsync(h_M, c->M, npx * 5 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return OFARN_OK;
+}
+
+int ofarn_stage_blur_solve(ofarn_ctx *c, const float *h_M, int w, int h, float *h_flow)
+{
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    if (!h_M || !h_flow) return fail(OFARN_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t npx = (size_t)w * h;
+    HIP_TRY(hipMemcpyAsync(c->M, h_M, npx * 5 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    launch_blur_solve(c->stream, c->M, c->flowA, w, h, 1, c->prm.winsize);
+    HIP_TRY(hipMemcpyAsync(h_flow, c->flowA, npx * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return OFARN_OK;
+}
+
+int ofarn_stage_flow_upsample(ofarn_ctx *c, const float *h_flow, int sw, int sh, int dw, int dh, float *h_out)
+{
+    int rc = check_size(c, dw, dh);
+    if (rc) return rc;
+    if ((rc = check_size(c, sw, sh))) return rc;
+    if (!h_flow || !h_out) return fail(OFARN_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<int> xo, yo;
+    std::vector<float> xa, ya;
+    resize_tables(sw, dw, xo, xa);
+    resize_tables(sh, dh, yo, ya);
+    int *d_xo = nullptr, *d_yo = nullptr;
+    float *d_xa = nullptr, *d_ya = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_xo, dw * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&d_xa, dw * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&d_yo, dh * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&d_ya, dh * sizeof(float)));
+    HIP_TRY(hipMemcpy(d_xo, xo.data(), dw * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_xa, xa.data(), dw * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_yo, yo.data(), dh * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_ya, ya.data(), dh * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(c->flowA, h_flow, (size_t)sw * sh * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    launch_flow_upsample(c->stream, c->flowA, sw, sh, c->flowB, dw, dh, 1, d_xo, d_xa, d_yo, d_ya,
+                         (float)(1. / c->prm.pyr_scale));
+    HIP_TRY(hipMemcpyAsync(h_out, c->flowB, (size_t)dw * dh * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_xo); (void)hipFree(d_xa); (void)hipFree(d_yo); (void)hipFree(d_ya);
+    return OFARN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// ofarn_internal.h -- shared declarations between the HIP kernels and the C-ABI host code.
+//
+// Data layout in HBM (all dense, row-major, x fastest):
+//   frames   uint8  [F][H][W]                full-resolution input frames
+//   tmp      float  [F][H][w_k][2]           row-filtered frame at the two source columns each
+//                                            level column samples (level build, stage A)
+//   I_k      float  [F][h_k][w_k]            level image
+//   R_k      float  [F][5][h_k][w_k]         polynomial expansion, channel-planar
+//                                            (channel order of optflowgf.cpp: y, x, yy, xx, xy)
+//   M_k      float  [P][5][h_k][w_k]         G11, G12, G22, h1, h2, channel-planar
+//   flow_k   float2 [P][h_k][w_k]            (dx, dy)
+// F = frames in the wave, P = pairs in the wave.  Pair p reads frames (2p, 2p+1) or (p, p+1).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ofarn {
+
+constexpr int kMaxPolyN = 15;
+constexpr int kBorder = 5;   // FarnebackUpdateMatrices: BORDER
+
+struct PolyCoef {
+    float g[kMaxPolyN + 1];
+    float xg[kMaxPolyN + 1];
+    float xxg[kMaxPolyN + 1];
+    double ig11, ig03, ig33, ig55;
+    int n;
+};
+
+// Stage A: level image = resize(GaussianBlur(float(frame)))
+void launch_level_hpass(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H,
+                        int nframes, const float *d_kern, int ksize, const int *d_xofs, int dw,
+                        float *tmp);
+void launch_level_vpass(hipStream_t s, const float *tmp, int H, int dw, int dh, int nframes,
+                        const float *d_kern, int ksize, const float *d_xa, const int *d_yofs,
+                        const float *d_ya, float *I);
+// Stage B: polynomial expansion
+void launch_polyexp(hipStream_t s, const float *I, float *R, int w, int h, int nframes,
+                    const PolyCoef &c);
+// Stage E: flow upsample (INTER_LINEAR) and scale by 1/pyr_scale
+void launch_flow_upsample(hipStream_t s, const float *src, int sw, int sh, float *dst, int dw, int dh,
+                          int npairs, const int *d_xofs, const float *d_xa, const int *d_yofs,
+                          const float *d_ya, float mul);
+// Stage C: update matrices.  R holds frames; pair p uses frames (p*fstep, p*fstep+1).
+void launch_update_matrices(hipStream_t s, const float *R, int fstep, const float *flow, float *M,
+                            int w, int h, int npairs);
+// Stage D: box average + 2x2 solve
+void launch_blur_solve(hipStream_t s, const float *M, float *flow, int w, int h, int npairs,
+                       int winsize);
+// Stage F: grid sample + vector filter + danger brightness.  d_pts int2[P] grid coordinates.
+int grid_filter_lds_bytes(int P);
+void launch_grid_filter(hipStream_t s, const float *flow, int w, int h, int npairs, const int *d_pts,
+                        int P, uint8_t *mask, uint8_t *v);
+
+}  // namespace ofarn

@@ -1,0 +1,411 @@
+"""Python host side of libofarn.so -- mirrors the reference's operator interface for its dense path.
+
+Reference interface mirrored (same names, keyword meaning, defaults and error behaviour):
+
+* ``calculate_optical_flow(prev, next, flow=None, pyr_scale=0.5, levels=3, winsize=15, iterations=3,
+  poly_n=5, poly_sigma=1.2, flags=0)``  -- DenseOF.py:127-157, a pass-through to
+  ``cv2.calcOpticalFlowFarneback`` (DenseOF.py:147-156); ``calcOpticalFlowFarneback`` is offered
+  under the cv2 name with cv2's positional order.
+* the measurement grid, vector filter and danger brightness of pathfinder_viewer.py:159-176,
+  204-217, 252-267, applied to the dense flow sampled at the grid (``flow[y, x]``, DenseOF.py:44-45).
+
+Everything numerical happens in hand-written HIP kernels behind the C-ABI of ``include/ofarn.h``;
+this module only validates arguments, owns NumPy output buffers and calls through ``ctypes``.
+There is no CPU fallback: if ``libofarn.so`` is missing or no GPU is visible, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libofarn.so")
+
+OFARN_OK = 0
+OFARN_E_INVALID = -1
+OFARN_E_UNSUPPORTED = -2
+OFARN_E_HIP = -3
+OFARN_E_NOMEM = -4
+OFARN_E_SIZE = -5
+
+PAIRS_INDEPENDENT = 0   # frames (2i, 2i+1)
+PAIRS_CONSECUTIVE = 1   # frames (i, i+1): video order, DenseOF.py:525 (prev_gray = gray)
+
+
+class OfarnParams(C.Structure):
+    """struct ofarn_params (include/ofarn.h): DenseOF.py:127-128 keywords + pathfinder_viewer.py:16 step."""
+    _fields_ = [("pyr_scale", C.c_double), ("levels", C.c_int), ("winsize", C.c_int),
+                ("iterations", C.c_int), ("poly_n", C.c_int), ("poly_sigma", C.c_double),
+                ("flags", C.c_int), ("grid_step", C.c_int)]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+_u8p = C.POINTER(C.c_uint8)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+_dp = C.POINTER(C.c_double)
+
+# every symbol include/ofarn.h declares: name -> (restype, argtypes)
+ABI = {
+    "ofarn_default_params": (None, [C.POINTER(OfarnParams)]),
+    "ofarn_create": (C.c_int, [C.POINTER(OfarnParams), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "ofarn_destroy": (None, [C.c_void_p]),
+    "ofarn_last_error": (C.c_char_p, []),
+    "ofarn_calc": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _fp]),
+    "ofarn_calc_batch": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _u8p, _u8p]),
+    "ofarn_calc_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ofarn_grid_points": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp]),
+    "ofarn_grid_filter": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, _u8p, _u8p]),
+    "ofarn_grid_filter_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]),
+    "ofarn_level_plan": (C.c_int, [C.POINTER(OfarnParams), C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _dp]),
+    "ofarn_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "ofarn_profile_read": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _dp, _dp]),
+    "ofarn_last_device_ms": (C.c_double, [C.c_void_p]),
+    "ofarn_workspace_bytes": (C.c_uint64, [C.c_void_p]),
+    "ofarn_version": (C.c_char_p, []),
+    "ofarn_stage_level_image": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, _fp]),
+    "ofarn_stage_polyexp": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, _fp]),
+    "ofarn_stage_update_matrices": (C.c_int, [C.c_void_p, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
+    "ofarn_stage_blur_solve": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, _fp]),
+    "ofarn_stage_flow_upsample": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+}
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.
+
+    The PyTorch-ROCm wheel bundles its own libamdhip64.so (soname libamdhip64.so.7) next to its own
+    libhsa-runtime64; libofarn.so needs ``libamdhip64.so.7`` too.  If libofarn pulled in the system
+    copy first, a later ``import torch`` would load a SECOND runtime and find no GPU (and tensors
+    from one runtime are foreign to the other).  Loading torch's copy first makes the dynamic
+    loader resolve libofarn's NEEDED entry to it by soname, so torch tensors, streams and libofarn
+    share one runtime.  Without torch installed the system runtime (/opt/rocm) is used."""
+    if os.environ.get("OFARN_SYSTEM_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass
+
+
+def load_library() -> C.CDLL:
+    """Loads libofarn.so.  Fails loudly if it has not been built: there is no fallback path."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"{LIB_PATH} is missing: build it with `python -m hackathonopticalflow_amd.build` "
+                    "(hipcc --offload-arch=gfx950).  hackathonopticalflow_amd has no CPU fallback.")
+            _share_hip_runtime_with_torch()
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in ABI.items():
+                fn = getattr(lib, name)   # AttributeError if the .so does not export the symbol
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+        return _lib
+
+
+def _raise(rc: int):
+    msg = load_library().ofarn_last_error().decode("utf-8", "replace")
+    if rc in (OFARN_E_INVALID, OFARN_E_SIZE):
+        raise ValueError(msg)
+    if rc == OFARN_E_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == OFARN_E_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def _check(rc: int):
+    if rc != OFARN_OK:
+        _raise(rc)
+
+
+def make_params(pyr_scale=0.5, levels=3, winsize=15, iterations=3, poly_n=5, poly_sigma=1.2, flags=0,
+                grid_step=30) -> OfarnParams:
+    return OfarnParams(float(pyr_scale), int(levels), int(winsize), int(iterations), int(poly_n),
+                       float(poly_sigma), int(flags), int(grid_step))
+
+
+def level_plan(width, height, **kw):
+    """[(w, h, ksize, sigma)] per scale, level 0 first (optflowgf.cpp calc(): levels+1 scales)."""
+    lib = load_library()
+    p = make_params(**kw)
+    cap = 64
+    lw, lh, ks = (C.c_int * cap)(), (C.c_int * cap)(), (C.c_int * cap)()
+    sg = (C.c_double * cap)()
+    n = lib.ofarn_level_plan(C.byref(p), width, height, cap, lw, lh, ks, sg)
+    if n < 0:
+        _raise(n)
+    return [(lw[i], lh[i], ks[i], sg[i]) for i in range(n)]
+
+
+def grid_points(width, height, step=30) -> np.ndarray:
+    """float32[P,2] (x, y), x-major: pathfinder_viewer.py:255-267."""
+    lib = load_library()
+    n = lib.ofarn_grid_points(width, height, step, None)
+    if n < 0:
+        _raise(n)
+    pts = np.empty((n, 2), np.float32)
+    lib.ofarn_grid_points(width, height, step, pts.ctypes.data_as(_fp))
+    return pts
+
+
+def _as_gray(a, name):
+    a = np.asarray(a)
+    if a.dtype != np.uint8:
+        raise ValueError(f"{name} must be uint8 (8-bit single-channel image), got {a.dtype}")
+    if a.ndim == 3 and a.shape[2] == 1:
+        a = a[:, :, 0]
+    if a.ndim != 2:
+        raise ValueError(f"{name} must be a single-channel 2-D image, got shape {a.shape}")
+    return a
+
+
+def _ptr(t):
+    """Device pointer of a torch tensor / anything with data_ptr(), or a raw int."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    return C.c_void_p(t.data_ptr())
+
+
+class FarnebackEngine:
+    """One ofarn_ctx: a GPU, a parameter set, a maximum frame size and wave size.
+
+    Not thread-safe (one context must not be used from two threads at once)."""
+
+    def __init__(self, max_width, max_height, max_batch=1, device=0, **params):
+        self._lib = load_library()
+        self.params = make_params(**params)
+        self.max_width, self.max_height, self.max_batch, self.device = max_width, max_height, max_batch, device
+        h = C.c_void_p()
+        _check(self._lib.ofarn_create(C.byref(self.params), device, max_width, max_height, max_batch, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ofarn_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ------------------------------------------------------------------ host-memory entry points
+    def calc(self, prev, next, flow=None) -> np.ndarray:
+        """cv2.calcOpticalFlowFarneback(prev, next, flow, ...) for this engine's parameters."""
+        prev, next = _as_gray(prev, "prev"), _as_gray(next, "next")
+        if prev.shape != next.shape:
+            raise ValueError(f"prev and next must have the same size, got {prev.shape} and {next.shape}")
+        h, w = prev.shape
+        if prev.strides[1] != 1 or prev.strides[0] != next.strides[0] or next.strides[1] != 1 or prev.strides[0] < w:
+            prev, next = np.ascontiguousarray(prev), np.ascontiguousarray(next)
+        if not (isinstance(flow, np.ndarray) and flow.dtype == np.float32 and flow.shape == (h, w, 2)
+                and flow.flags.c_contiguous):
+            flow = np.empty((h, w, 2), np.float32)
+        _check(self._lib.ofarn_calc(self._h, prev.ctypes.data_as(_u8p), next.ctypes.data_as(_u8p), w, h,
+                                    prev.strides[0], flow.ctypes.data_as(_fp)))
+        return flow
+
+    def calc_batch(self, frames, pairs_mode=PAIRS_INDEPENDENT, want_flow=True, want_danger=True):
+        """frames uint8[n_frames,H,W] -> (flow float32[n_pairs,H,W,2] | None, mask u8[n_pairs,P] | None,
+        v u8[n_pairs,P] | None)."""
+        frames = np.asarray(frames)
+        if frames.dtype != np.uint8 or frames.ndim != 3:
+            raise ValueError("frames must be uint8[n_frames, H, W]")
+        frames = np.ascontiguousarray(frames)
+        n, h, w = frames.shape
+        n_pairs = n - 1 if pairs_mode == PAIRS_CONSECUTIVE else n // 2
+        n_pairs = max(n_pairs, 0)
+        flow = np.empty((n_pairs, h, w, 2), np.float32) if want_flow else None
+        P = len(grid_points(w, h, self.params.grid_step)) if want_danger else 0
+        mask = np.zeros((n_pairs, P), np.uint8) if want_danger else None
+        v = np.zeros((n_pairs, P), np.uint8) if want_danger else None
+        _check(self._lib.ofarn_calc_batch(
+            self._h, frames.ctypes.data_as(_u8p), n, w, h, pairs_mode,
+            flow.ctypes.data_as(_fp) if want_flow else None,
+            mask.ctypes.data_as(_u8p) if want_danger else None,
+            v.ctypes.data_as(_u8p) if want_danger else None))
+        return flow, mask, v
+
+    def danger_map(self, flow):
+        """Grid vector filter + V on existing dense flow float32[n,H,W,2] (or [H,W,2])."""
+        flow = np.ascontiguousarray(flow, np.float32)
+        single = flow.ndim == 3
+        if single:
+            flow = flow[None]
+        n, h, w, two = flow.shape
+        if two != 2:
+            raise ValueError("flow must be float32[..., H, W, 2]")
+        P = len(grid_points(w, h, self.params.grid_step))
+        mask = np.zeros((n, P), np.uint8)
+        v = np.zeros((n, P), np.uint8)
+        _check(self._lib.ofarn_grid_filter(self._h, flow.ctypes.data_as(_fp), n, w, h,
+                                           mask.ctypes.data_as(_u8p), v.ctypes.data_as(_u8p)))
+        return (mask[0], v[0]) if single else (mask, v)
+
+    # ------------------------------------------------------------------ device-memory entry points
+    def calc_batch_device(self, d_frames, n_frames, width, height, pairs_mode=PAIRS_INDEPENDENT,
+                          d_flow=None, d_mask=None, d_v=None, stream=None):
+        """Device-resident batch: arguments are torch CUDA tensors (or raw device addresses).
+        Enqueues on `stream` (raw hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream;
+        None = the engine's own stream) and does not synchronise."""
+        _check(self._lib.ofarn_calc_batch_device(self._h, _ptr(d_frames), n_frames, width, height, pairs_mode,
+                                                 _ptr(d_flow), _ptr(d_mask), _ptr(d_v),
+                                                 C.c_void_p(stream) if stream else None))
+
+    def danger_map_device(self, d_flow, n, width, height, d_mask, d_v, stream=None):
+        _check(self._lib.ofarn_grid_filter_device(self._h, _ptr(d_flow), n, width, height, _ptr(d_mask),
+                                                  _ptr(d_v), C.c_void_p(stream) if stream else None))
+
+    # ------------------------------------------------------------------ per-kernel timing
+    STAGES = ("level_hpass", "level_vpass", "polyexp", "flow_upsample", "update_matrices", "blur_solve",
+              "grid_filter")
+
+    def profile_enable(self, on=True):
+        _check(self._lib.ofarn_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self):
+        """[{stage, level, launches, ms, units}] since the last read (waits for the recorded events)."""
+        cap = 7 * 32
+        st, lv, ln = (C.c_int * cap)(), (C.c_int * cap)(), (C.c_int * cap)()
+        ms, un = (C.c_double * cap)(), (C.c_double * cap)()
+        n = self._lib.ofarn_profile_read(self._h, cap, st, lv, ln, ms, un)
+        if n < 0:
+            _raise(n)
+        return [dict(stage=self.STAGES[st[i]], level=lv[i], launches=ln[i], ms=ms[i], units=un[i])
+                for i in range(min(n, cap))]
+
+    # ------------------------------------------------------------------ introspection
+    @property
+    def last_device_ms(self) -> float:
+        return float(self._lib.ofarn_last_device_ms(self._h))
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self._lib.ofarn_workspace_bytes(self._h))
+
+    # ------------------------------------------------------------------ single stages (parity tests)
+    def stage_level_image(self, img, k):
+        img = np.ascontiguousarray(_as_gray(img, "img"))
+        h, w = img.shape
+        plan = level_plan(w, h, **_params_dict(self.params))
+        lw, lh = plan[k][0], plan[k][1]
+        out = np.empty((lh, lw), np.float32)
+        _check(self._lib.ofarn_stage_level_image(self._h, img.ctypes.data_as(_u8p), w, h, k, out.ctypes.data_as(_fp)))
+        return out
+
+    def stage_polyexp(self, I):
+        I = np.ascontiguousarray(I, np.float32)
+        h, w = I.shape
+        R = np.empty((5, h, w), np.float32)
+        _check(self._lib.ofarn_stage_polyexp(self._h, I.ctypes.data_as(_fp), w, h, R.ctypes.data_as(_fp)))
+        return R
+
+    def stage_update_matrices(self, R0, R1, flow):
+        R0, R1 = np.ascontiguousarray(R0, np.float32), np.ascontiguousarray(R1, np.float32)
+        flow = np.ascontiguousarray(flow, np.float32)
+        h, w = flow.shape[:2]
+        M = np.empty((5, h, w), np.float32)
+        _check(self._lib.ofarn_stage_update_matrices(self._h, R0.ctypes.data_as(_fp), R1.ctypes.data_as(_fp),
+                                                     flow.ctypes.data_as(_fp), w, h, M.ctypes.data_as(_fp)))
+        return M
+
+    def stage_blur_solve(self, M):
+        M = np.ascontiguousarray(M, np.float32)
+        _, h, w = M.shape
+        flow = np.empty((h, w, 2), np.float32)
+        _check(self._lib.ofarn_stage_blur_solve(self._h, M.ctypes.data_as(_fp), w, h, flow.ctypes.data_as(_fp)))
+        return flow
+
+    def stage_flow_upsample(self, flow, dw, dh):
+        flow = np.ascontiguousarray(flow, np.float32)
+        sh, sw = flow.shape[:2]
+        out = np.empty((dh, dw, 2), np.float32)
+        _check(self._lib.ofarn_stage_flow_upsample(self._h, flow.ctypes.data_as(_fp), sw, sh, dw, dh,
+                                                   out.ctypes.data_as(_fp)))
+        return out
+
+
+def _params_dict(p: OfarnParams):
+    return {f: getattr(p, f) for f, _ in OfarnParams._fields_}
+
+
+# ---------------------------------------------------------------------------------------------
+# Drop-in functions with the reference's names
+# ---------------------------------------------------------------------------------------------
+_engines: dict = {}
+_engines_lock = threading.Lock()
+
+
+def _engine_for(h, w, device, **params) -> FarnebackEngine:
+    key = (h, w, device, tuple(sorted(params.items())))
+    with _engines_lock:
+        eng = _engines.get(key)
+        if eng is None:
+            if len(_engines) >= 8:   # bounded cache: drop the oldest context
+                _engines.pop(next(iter(_engines))).close()
+            eng = _engines[key] = FarnebackEngine(w, h, 1, device, **params)
+        return eng
+
+
+def calculate_optical_flow(prev, next, flow=None, pyr_scale=0.5, levels=3, winsize=15, iterations=3,
+                           poly_n=5, poly_sigma=1.2, flags=0, device=0):
+    """Drop-in for DenseOF.py:127-157 ``calculate_optical_flow``.
+
+    prev, next: uint8[H,W] grayscale frames.  Returns float32[H,W,2]; channel 0 = dx, channel 1 = dy.
+    Raises ValueError where cv2 raises cv2.error (size/channel mismatch, pyr_scale >= 1)."""
+    prev_a, next_a = _as_gray(prev, "prev"), _as_gray(next, "next")
+    if prev_a.shape != next_a.shape:
+        raise ValueError(f"prev and next must have the same size, got {prev_a.shape} and {next_a.shape}")
+    h, w = prev_a.shape
+    eng = _engine_for(h, w, device, pyr_scale=float(pyr_scale), levels=int(levels), winsize=int(winsize),
+                      iterations=int(iterations), poly_n=int(poly_n), poly_sigma=float(poly_sigma),
+                      flags=int(flags))
+    return eng.calc(prev_a, next_a, flow)
+
+
+def calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags):
+    """cv2.calcOpticalFlowFarneback with cv2's positional order (DenseOF.py:147-156)."""
+    return calculate_optical_flow(prev, next, flow, pyr_scale, levels, winsize, iterations, poly_n,
+                                  poly_sigma, flags)
+
+
+def danger_map(flow, step=30, device=0):
+    """Dense adaptation of pathfinder_viewer.py:159-176 + 204-217: (mask u8[P], v u8[P]) for one flow field."""
+    flow = np.asarray(flow)
+    h, w = flow.shape[-3], flow.shape[-2]
+    eng = _engine_for(h, w, device, grid_step=int(step))
+    return eng.danger_map(flow)
+
+
+def close_cached_engines():
+    with _engines_lock:
+        for e in _engines.values():
+            e.close()
+        _engines.clear()

@@ -1,0 +1,148 @@
+/*
+ * ofarn.h -- C-ABI of libofarn.so: dense Farneback optical flow + grid vector filter on MI355X.
+ *
+ * This is the drop-in boundary for the one hot path of spirinis/HackathonOpticalFlow:
+ *
+ *   calculate_optical_flow(prev, next, flow=None, pyr_scale=0.5, levels=3, winsize=15,
+ *                          iterations=3, poly_n=5, poly_sigma=1.2, flags=0) -> float32[H,W,2]
+ *       reference: DenseOF.py:127-157, which forwards to cv2.calcOpticalFlowFarneback
+ *       (DenseOF.py:147-156); called once per frame at DenseOF.py:520.
+ *
+ * followed by the reference's own sparse-grid vector filter and danger brightness
+ *       reference: pathfinder_viewer.py:159-176 (filter), :204-217 (V), :252-267 (grid).
+ *
+ * The reference is pure Python over the cv2 wheel, so it has no FFI of its own for this path; the
+ * entry points below are what a ctypes binding in DenseOF.py would call instead of cv2 (the stub
+ * is shown in INTEGRATION.md).  Plain pointers and sizes only; no C++ or torch types; no
+ * exceptions cross this boundary.  Every function returns OFARN_OK (0) or a negative error code
+ * and leaves a message for ofarn_last_error() (thread local).
+ *
+ * Pointer naming: h_* = host memory, d_* = device (HBM) memory of the context's GPU.
+ * A context is bound to one GPU and must not be used from two threads at once.
+ */
+#ifndef OFARN_H
+#define OFARN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFARN_OK 0
+#define OFARN_E_INVALID (-1)   /* bad argument (maps to cv2.error / ValueError)                 */
+#define OFARN_E_UNSUPPORTED (-2) /* valid for cv2 but not built yet (flags != 0) */
+#define OFARN_E_HIP (-3)       /* HIP runtime failure                                            */
+#define OFARN_E_NOMEM (-4)     /* workspace does not fit                                         */
+#define OFARN_E_SIZE (-5)      /* frame or batch larger than the context was created for         */
+
+/* pairs_mode of the batch entry points */
+#define OFARN_PAIRS_INDEPENDENT 0 /* frames (2i, 2i+1) form pair i; n_pairs = n_frames/2          */
+#define OFARN_PAIRS_CONSECUTIVE 1 /* frames (i, i+1) form pair i (video order, DenseOF.py:525: */
+                                  /* prev_gray = gray); n_pairs = n_frames-1                     */
+
+/* The seven keyword arguments of DenseOF.py:127-128 (== cv2.calcOpticalFlowFarneback) plus the
+ * measurement-grid step of pathfinder_viewer.py:16. */
+typedef struct ofarn_params {
+    double pyr_scale;   /* < 1                                        default 0.5 */
+    int levels;         /* pyramid reductions; levels+1 scales run    default 3   */
+    int winsize;        /* averaging window, >= 2                     default 15  */
+    int iterations;     /* per level                                  default 3   */
+    int poly_n;         /* polynomial-expansion radius (2n+1 taps)    default 5   */
+    double poly_sigma;  /*                                            default 1.2 */
+    int flags;          /* must be 0                                  default 0   */
+    int grid_step;      /* danger-map grid step in pixels             default 30  */
+} ofarn_params;
+
+typedef struct ofarn_ctx ofarn_ctx;
+
+/* Fills *p with the reference defaults (DenseOF.py:127-128, pathfinder_viewer.py:16). */
+void ofarn_default_params(ofarn_params *p);
+
+/* Creates a context on GPU `device` able to process frames up to max_w x max_h, in waves of up
+ * to max_batch pairs resident at once.  Replaces: constructing cv::FarnebackOpticalFlow inside
+ * cv2.calcOpticalFlowFarneback (DenseOF.py:147). */
+int ofarn_create(const ofarn_params *params, int device, int max_w, int max_h, int max_batch,
+                 ofarn_ctx **out);
+void ofarn_destroy(ofarn_ctx *ctx);
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char *ofarn_last_error(void);
+
+/* One frame pair, host memory in, host memory out; synchronous.
+ * Replaces: cv2.calcOpticalFlowFarneback(prev, next, None, ...) at DenseOF.py:147-156.
+ * h_prev/h_next: uint8, `stride` bytes per row.  h_flow: float32[h][w][2], (dx, dy) per pixel. */
+int ofarn_calc(ofarn_ctx *ctx, const uint8_t *h_prev, const uint8_t *h_next, int w, int h,
+               int stride, float *h_flow);
+
+/* A batch of frames, host memory; synchronous.  h_frames: uint8[n_frames][h][w] dense.
+ * Any of h_flow (float32[n_pairs][h][w][2]), h_mask, h_v (uint8[n_pairs][P]) may be NULL.
+ * Replaces: the per-frame loop DenseOF.py:491-525 plus the filter pathfinder_viewer.py:159-176
+ * and the V values of pathfinder_viewer.py:204-217 applied to the dense flow sampled at the grid. */
+int ofarn_calc_batch(ofarn_ctx *ctx, const uint8_t *h_frames, int n_frames, int w, int h,
+                     int pairs_mode, float *h_flow, uint8_t *h_mask, uint8_t *h_v);
+
+/* Same, device-resident: all pointers are HBM addresses on the context's GPU; work is enqueued on
+ * `hip_stream` (a hipStream_t, NULL = the context's own stream) and NOT synchronised. */
+int ofarn_calc_batch_device(ofarn_ctx *ctx, const uint8_t *d_frames, int n_frames, int w, int h,
+                            int pairs_mode, float *d_flow, uint8_t *d_mask, uint8_t *d_v,
+                            void *hip_stream);
+
+/* Measurement grid of pathfinder_viewer.py:255-267.  Returns P (number of points, x-major order);
+ * if h_pts != NULL writes float32[P][2] = (x, y). */
+int ofarn_grid_points(int w, int h, int step, float *h_pts);
+
+/* Vector filter + danger brightness on existing dense flow (pathfinder_viewer.py:159-176, 204-217).
+ * flow: float32[n][h][w][2]; mask, v: uint8[n][P]; v is 0 where mask is 0. */
+int ofarn_grid_filter(ofarn_ctx *ctx, const float *h_flow, int n, int w, int h, uint8_t *h_mask,
+                      uint8_t *h_v);
+int ofarn_grid_filter_device(ofarn_ctx *ctx, const float *d_flow, int n, int w, int h,
+                             uint8_t *d_mask, uint8_t *d_v, void *hip_stream);
+
+/* Level plan for a frame size: writes up to cap entries of (w, h, ksize) and sigma per level,
+ * level 0 first; returns the number of scales (levels+1 after cropping).  optflowgf.cpp calc(). */
+int ofarn_level_plan(const ofarn_params *params, int w, int h, int cap, int *lw, int *lh, int *ksize,
+                     double *sigma);
+
+/* Device time in milliseconds of the most recent host-pointer call (hipEvent, H2D/D2H excluded). */
+double ofarn_last_device_ms(const ofarn_ctx *ctx);
+
+/* Per-kernel timing.  While enabled, every kernel launch is bracketed by a hipEvent pair recorded
+ * on the stream the kernel is launched on.  ofarn_profile_read() waits for the pending events,
+ * then returns one row per (stage, pyramid level) seen since the last read: number of launches,
+ * summed device milliseconds and summed work units (level pixels x frames for stages A/B, level
+ * pixels x pairs for C/D/E, grid points x pairs for F).  Returns the number of rows (may exceed
+ * cap; only cap are written) and resets the accumulators. */
+#define OFARN_STAGE_LEVEL_H 0     /* A: u8->f32 + Gaussian row pass at sampled columns */
+#define OFARN_STAGE_LEVEL_V 1     /* A: Gaussian column pass + bilinear resize          */
+#define OFARN_STAGE_POLYEXP 2     /* B: FarnebackPolyExp                                */
+#define OFARN_STAGE_UPSAMPLE 3    /* E: flow resize x 1/pyr_scale                       */
+#define OFARN_STAGE_MATRICES 4    /* C: FarnebackUpdateMatrices                         */
+#define OFARN_STAGE_BLUR_SOLVE 5  /* D: FarnebackUpdateFlow_Blur                        */
+#define OFARN_STAGE_GRID_FILTER 6 /* F: grid sample + vector filter + V                 */
+#define OFARN_STAGE_COUNT 7
+int ofarn_profile_enable(ofarn_ctx *ctx, int on);
+int ofarn_profile_read(ofarn_ctx *ctx, int cap, int *stage, int *level, int *launches, double *ms,
+                       double *units);
+
+/* Bytes of HBM workspace held by the context. */
+uint64_t ofarn_workspace_bytes(const ofarn_ctx *ctx);
+
+/* Library build string: "ofarn <version> gfx950 ...". */
+const char *ofarn_version(void);
+
+/* ---- single-stage entry points (host arrays in/out, one image; used by the parity tests to
+ * compare each HIP kernel with the oracle stage by stage).  Channel-planar float32 [5][h][w]
+ * for R and M; interleaved float32 [h][w][2] for flow. -------------------------------------- */
+int ofarn_stage_level_image(ofarn_ctx *ctx, const uint8_t *h_img, int w, int h, int k, float *h_out);
+int ofarn_stage_polyexp(ofarn_ctx *ctx, const float *h_img, int w, int h, float *h_R);
+int ofarn_stage_update_matrices(ofarn_ctx *ctx, const float *h_R0, const float *h_R1,
+                                const float *h_flow, int w, int h, float *h_M);
+int ofarn_stage_blur_solve(ofarn_ctx *ctx, const float *h_M, int w, int h, float *h_flow);
+int ofarn_stage_flow_upsample(ofarn_ctx *ctx, const float *h_flow, int sw, int sh, int dw, int dh,
+                              float *h_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFARN_H */

@@ -1,0 +1,42 @@
+"""Regenerates tests/golden/*.npz from the CPU oracle (oracle/farneback_oracle.c + the NumPy filter).
+
+    python tests/golden/make_golden.py
+
+The reference ships no fixtures for its Farneback path and cv2 cannot be imported here (SURVEY.md
+8c), so these vectors are outputs of the repo's own oracle, PARITY UNPINNED against real OpenCV.
+They pin (a) the oracle against accidental change and (b) the HIP path on the GPU box, where they
+are compared bit for bit (flow_direct) and within tolerance (flow_running = OpenCV's literal order).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from hackathonopticalflow_amd.synth import translated_pair  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+CASES = {
+    # name: (height, width, seed, farneback kwargs)
+    "g160x120_L2": (120, 160, 501, dict(levels=2)),
+    "g97x83_odd": (83, 97, 502, dict(levels=1, winsize=9, poly_n=7, poly_sigma=1.5)),
+    "g192x144_scale08": (144, 192, 503, dict(levels=3, pyr_scale=0.8, iterations=2, winsize=8)),
+}
+
+
+def main():
+    out = os.path.dirname(os.path.abspath(__file__))
+    for name, (h, w, seed, kw) in CASES.items():
+        prev, nxt, shift = translated_pair(h, w, seed, max_shift=4)
+        fd = O.farneback(prev, nxt, box_mode=O.BOX_DIRECT, **kw)
+        fr = O.farneback(prev, nxt, box_mode=O.BOX_RUNNING, **kw)
+        mask, v = O.danger_map_numpy(fd, w, h, 30)
+        np.savez_compressed(os.path.join(out, name + ".npz"), prev=prev, next=nxt, shift=np.int64(shift),
+                            flow_direct=fd, flow_running=fr, mask=mask, v=v,
+                            params=np.array(repr(sorted(kw.items()))))
+        print(name, fd.shape, "max |direct-running| =", float(np.abs(fd - fr).max()), "kept", int(mask.sum()))
+
+
+if __name__ == "__main__":
+    main()

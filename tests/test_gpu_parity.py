@@ -1,0 +1,256 @@
+"""GPU parity: the HIP path (through the C-ABI of include/ofarn.h) against the CPU oracle.
+
+Bar (north_star): flow within a stated EPE tolerance of the OpenCV-algorithm oracle; danger-point
+index sets bit-identical.  What is asserted here:
+  * every stage, and the whole pipeline, BIT-EXACT against the oracle run with the direct box-sum
+    order (oracle BOX_DIRECT: same IEEE operations in the same order as the kernels);
+  * against the oracle in OpenCV's literal running-sum order: mean EPE <= 1e-5 px and
+    max EPE <= 1e-3 px (TOL_* below) -- the only difference is the summation order of the box filter;
+  * danger mask bit-exact against the reference's NumPy filter on the same flow.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from hackathonopticalflow_amd.synth import translated_pair, translated_pairs
+
+pytestmark = pytest.mark.gpu
+
+TOL_MEAN_EPE = 1e-5   # px, GPU vs oracle in OpenCV's running-sum order
+TOL_MAX_EPE = 1e-3    # px
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.fixture(scope="module")
+def H():
+    import hackathonopticalflow_amd as H
+    H.load_library()
+    return H
+
+
+def planar(a):   # oracle [h,w,5] -> device layout [5,h,w]
+    return np.ascontiguousarray(np.moveaxis(a, -1, 0))
+
+
+def epe(a, b):
+    return np.linalg.norm(a.astype(np.float64) - b.astype(np.float64), axis=-1)
+
+
+# ------------------------------------------------------------------------------------ stages
+@pytest.mark.parametrize("w,h,levels", [(640, 480, 3), (333, 251, 2), (1920, 1080, 5)])
+def test_stage_level_image_bit_exact(H, oracle, w, h, levels):
+    img, _, _ = translated_pair(h, w, 7)
+    with H.FarnebackEngine(w, h, 1, levels=levels) as eng:
+        for k, (lw, lh, ks, sg) in enumerate(H.level_plan(w, h, levels=levels)):
+            assert (lw, lh, sg, ks) == oracle.level_geom(w, h, 0.5, k)
+            got = eng.stage_level_image(img, k)
+            ref = oracle.level_image(img, ks, sg, lw, lh)
+            np.testing.assert_array_equal(got, ref, err_msg=f"level {k}")
+
+
+@pytest.mark.parametrize("w,h,n,sigma", [(320, 240, 5, 1.2), (97, 83, 7, 1.5), (64, 33, 3, 0.0), (200, 40, 5, 1.1)])
+def test_stage_polyexp_bit_exact(H, oracle, w, h, n, sigma):
+    rng = np.random.default_rng(1)
+    I = rng.uniform(0, 255, (h, w)).astype(np.float32)
+    with H.FarnebackEngine(w, h, 1, poly_n=n, poly_sigma=sigma) as eng:
+        got = eng.stage_polyexp(I)
+    np.testing.assert_array_equal(got, planar(oracle.polyexp(I, n, sigma)))
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (97, 83), (33, 40)])
+def test_stage_update_matrices_bit_exact(H, oracle, w, h):
+    rng = np.random.default_rng(2)
+    R0 = rng.standard_normal((h, w, 5)).astype(np.float32)
+    R1 = rng.standard_normal((h, w, 5)).astype(np.float32)
+    flow = (rng.standard_normal((h, w, 2)) * 4).astype(np.float32)
+    flow[0, :5] = -9          # out-of-bounds branch
+    flow[-1, -5:] = 9
+    flow[5, 5] = (0.0, 0.0)
+    with H.FarnebackEngine(w, h, 1) as eng:
+        got = eng.stage_update_matrices(planar(R0), planar(R1), flow)
+    np.testing.assert_array_equal(got, planar(oracle.update_matrices(R0, R1, flow)))
+
+
+@pytest.mark.parametrize("w,h,winsize", [(320, 240, 15), (97, 83, 9), (70, 50, 8), (40, 33, 3), (64, 48, 41)])
+def test_stage_blur_solve_bit_exact(H, oracle, w, h, winsize):
+    rng = np.random.default_rng(3)
+    M = (rng.standard_normal((h, w, 5)) * 10).astype(np.float32)
+    z5, z2 = np.zeros((h, w, 5), np.float32), np.zeros((h, w, 2), np.float32)
+    ref, _ = oracle.update_flow_blur(z5, z5, z2, M, winsize, False, oracle.BOX_DIRECT)
+    with H.FarnebackEngine(w, h, 1, winsize=winsize) as eng:
+        got = eng.stage_blur_solve(planar(M))
+    np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("sw,sh,dw,dh", [(160, 120, 320, 240), (60, 34, 120, 68), (120, 68, 240, 135), (49, 42, 97, 83)])
+def test_stage_flow_upsample_bit_exact(H, oracle, sw, sh, dw, dh):
+    rng = np.random.default_rng(4)
+    f = (rng.standard_normal((sh, sw, 2)) * 3).astype(np.float32)
+    with H.FarnebackEngine(dw, dh, 1) as eng:
+        got = eng.stage_flow_upsample(f, dw, dh)
+    np.testing.assert_array_equal(got, oracle.resize_linear(f, dw, dh) * np.float32(2))
+
+
+# ------------------------------------------------------------------------------------ pipeline
+CASES = [
+    # (w, h, seed, kwargs)   -- first row is BASELINE config 1 (640x480, DenseOF.py defaults)
+    (640, 480, 1001, {}),
+    (333, 251, 11, dict(levels=2)),
+    (200, 160, 12, dict(levels=0)),
+    (256, 192, 13, dict(levels=4, pyr_scale=0.8, winsize=8, iterations=2)),
+    (180, 130, 14, dict(levels=1, poly_n=7, poly_sigma=1.5, winsize=21, iterations=1)),
+    (64, 64, 15, dict(levels=5)),          # cropped by min_size to 1 reduction
+]
+
+
+@pytest.mark.parametrize("w,h,seed,kw", CASES)
+def test_pipeline_vs_oracle(H, oracle, w, h, seed, kw):
+    prev, nxt, _ = translated_pair(h, w, seed, max_shift=5)
+    got = H.calculate_optical_flow(prev, nxt, **kw)
+    assert got.shape == (h, w, 2) and got.dtype == np.float32
+    np.testing.assert_array_equal(got, oracle.farneback(prev, nxt, box_mode=oracle.BOX_DIRECT, **kw))
+    e = epe(got, oracle.farneback(prev, nxt, box_mode=oracle.BOX_RUNNING, **kw))
+    assert e.mean() <= TOL_MEAN_EPE and e.max() <= TOL_MAX_EPE, (e.mean(), e.max())
+
+
+def test_pipeline_1080p_L5_config2(H, oracle):
+    """BASELINE config 2: one 1920x1080 pair, levels=5, iterations=3, seed 2001."""
+    prev, nxt, (tx, ty) = translated_pair(1080, 1920, 2001)
+    got = H.calculate_optical_flow(prev, nxt, levels=5)
+    ref = oracle.farneback(prev, nxt, levels=5, box_mode=oracle.BOX_DIRECT)
+    np.testing.assert_array_equal(got, ref)
+    e = epe(got, oracle.farneback(prev, nxt, levels=5))
+    assert e.mean() <= TOL_MEAN_EPE and e.max() <= TOL_MAX_EPE, (e.mean(), e.max())
+    gt = epe(got[32:-32, 32:-32], np.float32([tx, ty])[None, None])
+    assert gt.mean() < 0.1
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_golden_fixtures(H, path):
+    g = np.load(path, allow_pickle=False)
+    kw = dict(eval(str(g["params"])))
+    got = H.calculate_optical_flow(g["prev"], g["next"], **kw)
+    np.testing.assert_array_equal(got, g["flow_direct"])
+    e = epe(got, g["flow_running"])
+    assert e.mean() <= TOL_MEAN_EPE and e.max() <= TOL_MAX_EPE
+    mask, v = H.danger_map(got, 30)
+    np.testing.assert_array_equal(mask, g["mask"])
+    assert (v != g["v"]).sum() <= 1
+
+
+def test_constant_and_flow_reuse(H):
+    img = np.full((96, 128), 200, np.uint8)
+    out = np.full((96, 128, 2), 7, np.float32)
+    ret = H.calculate_optical_flow(img, img, out, levels=1)
+    assert ret is out and np.all(out == 0)
+    # cv2 positional order
+    ret2 = H.calcOpticalFlowFarneback(img, img, None, 0.5, 1, 15, 3, 5, 1.2, 0)
+    assert np.all(ret2 == 0)
+
+
+def test_strided_input(H, oracle):
+    big_p, big_n, _ = translated_pair(200, 300, 31)
+    prev, nxt = big_p[10:170, 20:260], big_n[10:170, 20:260]    # non-contiguous views
+    got = H.calculate_optical_flow(prev, nxt, levels=2)
+    ref = oracle.farneback(np.ascontiguousarray(prev), np.ascontiguousarray(nxt), levels=2, box_mode=oracle.BOX_DIRECT)
+    np.testing.assert_array_equal(got, ref)
+
+
+# ------------------------------------------------------------------------------------ batch + danger map
+def test_batch_modes_and_waves(H, oracle):
+    h, w, n_pairs = 120, 160, 5
+    frames, _ = translated_pairs(n_pairs, h, w, 3000, max_shift=4)
+    kw = dict(levels=2)
+    ref = np.stack([oracle.farneback(frames[2 * i], frames[2 * i + 1], box_mode=oracle.BOX_DIRECT, **kw)
+                    for i in range(n_pairs)])
+    for wave in (1, 2, 8):
+        with H.FarnebackEngine(w, h, wave, **kw) as eng:
+            flow, mask, v = eng.calc_batch(frames, H.PAIRS_INDEPENDENT)
+            np.testing.assert_array_equal(flow, ref)
+            for i in range(n_pairs):
+                m_ref, v_ref = oracle.danger_map_numpy(flow[i], w, h, 30)
+                np.testing.assert_array_equal(mask[i], m_ref)
+                assert (v[i] != v_ref).sum() <= 1
+            # video order: pair i = frames (i, i+1)
+            flow_c, _, _ = eng.calc_batch(frames[:6], H.PAIRS_CONSECUTIVE, want_danger=False)
+            assert flow_c.shape[0] == 5
+            np.testing.assert_array_equal(flow_c[0], ref[0])
+            np.testing.assert_array_equal(flow_c[2], ref[1])
+            mid = oracle.farneback(frames[1], frames[2], box_mode=oracle.BOX_DIRECT, **kw)
+            np.testing.assert_array_equal(flow_c[1], mid)
+
+
+def test_batch_empty_and_ragged(H):
+    with H.FarnebackEngine(160, 120, 4, levels=1) as eng:
+        flow, mask, v = eng.calc_batch(np.zeros((0, 120, 160), np.uint8))
+        assert flow.shape == (0, 120, 160, 2) and mask.shape[0] == 0
+        flow, _, _ = eng.calc_batch(np.zeros((1, 120, 160), np.uint8), H.PAIRS_CONSECUTIVE)
+        assert flow.shape[0] == 0
+        with pytest.raises(ValueError):
+            eng.calc_batch(np.zeros((3, 120, 160), np.uint8), H.PAIRS_INDEPENDENT)   # odd frame count
+        with pytest.raises(ValueError):
+            eng.calc_batch(np.zeros((2, 500, 500), np.uint8))                          # larger than ctx
+
+
+@pytest.mark.parametrize("w,h,step", [(1920, 1080, 30), (640, 480, 30), (1000, 700, 14)])
+def test_danger_map_mask_bit_exact_random_flow(H, oracle, w, h, step):
+    rng = np.random.default_rng(w)
+    flows = (rng.standard_normal((3, h, w, 2)) * np.float32([0.05, 2, 30])[:, None, None, None]).astype(np.float32)
+    flows[1, ::2] = 0     # ties / exact zeros at many grid points
+    with H.FarnebackEngine(w, h, 1, grid_step=step) as eng:
+        mask, v = eng.danger_map(flows)
+    nbad = 0
+    for i in range(3):
+        m_ref, v_ref = oracle.danger_map_numpy(flows[i], w, h, step)
+        np.testing.assert_array_equal(mask[i], m_ref)
+        nbad += int((v[i] != v_ref).sum())
+    # V goes through atan2f/cosf/sinf then truncation: library-specific last ulp
+    assert nbad <= 0.002 * mask.size + 1
+
+
+def test_device_resident_batch_torch(H, oracle):
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available()
+    h, w, n_pairs = 120, 160, 6
+    frames, _ = translated_pairs(n_pairs, h, w, 4000, max_shift=4)
+    P = len(H.grid_points(w, h, 30))
+    d_frames = torch.from_numpy(frames).cuda()
+    d_flow = torch.empty((n_pairs, h, w, 2), dtype=torch.float32, device="cuda")
+    d_mask = torch.zeros((n_pairs, P), dtype=torch.uint8, device="cuda")
+    d_v = torch.zeros((n_pairs, P), dtype=torch.uint8, device="cuda")
+    with H.FarnebackEngine(w, h, 4, levels=2) as eng:
+        st = torch.cuda.current_stream().cuda_stream
+        eng.calc_batch_device(d_frames, 2 * n_pairs, w, h, H.PAIRS_INDEPENDENT, d_flow, d_mask, d_v, stream=st)
+        torch.cuda.synchronize()
+        flow = d_flow.cpu().numpy()
+        for i in range(n_pairs):
+            ref = oracle.farneback(frames[2 * i], frames[2 * i + 1], levels=2, box_mode=oracle.BOX_DIRECT)
+            np.testing.assert_array_equal(flow[i], ref)
+            m_ref, _ = oracle.danger_map_numpy(flow[i], w, h, 30)
+            np.testing.assert_array_equal(d_mask[i].cpu().numpy(), m_ref)
+        # danger maps only (flow kept internal)
+        d_mask2 = torch.zeros_like(d_mask)
+        d_v2 = torch.zeros_like(d_v)
+        eng.calc_batch_device(d_frames, 2 * n_pairs, w, h, H.PAIRS_INDEPENDENT, None, d_mask2, d_v2, stream=st)
+        torch.cuda.synchronize()
+        assert torch.equal(d_mask, d_mask2) and torch.equal(d_v, d_v2)
+
+
+# ------------------------------------------------------------------------------------ errors
+def test_argument_errors(H):
+    a = np.zeros((64, 64), np.uint8)
+    with pytest.raises(ValueError):
+        H.calculate_optical_flow(a, np.zeros((64, 65), np.uint8))
+    with pytest.raises(ValueError):
+        H.calculate_optical_flow(a.astype(np.float32), a)
+    with pytest.raises(ValueError):
+        H.calculate_optical_flow(np.zeros((64, 64, 3), np.uint8), a)
+    with pytest.raises(ValueError):
+        H.calculate_optical_flow(a, a, pyr_scale=1.0)
+    with pytest.raises(ValueError):
+        H.calculate_optical_flow(a, a, winsize=1)
+    with pytest.raises(NotImplementedError):
+        H.calculate_optical_flow(a, a, flags=256)
