@@ -41,6 +41,7 @@ STAGE_BYTES = {
     "blur_solve": 28.0,       # M 20 in, flow 8 out
     "flow_upsample": 10.0,    # 8 B out + 8 B/4 in
     "level_vpass": 4.0,       # level image out (the frame read is charged to level_hpass)
+    "flow_iter": 96.0,        # fused C + D: 68 + 28 (M no longer reaches HBM; SURVEY 8(d) keeps the figure)
 }
 
 
@@ -121,6 +122,7 @@ def main():
     ap.add_argument("--unique", type=int, default=32, help="distinct synthetic pairs generated, then tiled")
     ap.add_argument("--cpu-sample", type=int, default=16, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel hipEvent timing")
+    ap.add_argument("--prof-table", action="store_true", help="print per-(stage, level) timing rows to stderr")
     args = ap.parse_args()
 
     import torch
@@ -188,6 +190,12 @@ def main():
             dist.destroy_process_group()
         return
 
+    if args.prof_table:
+        for r in sorted(prof, key=lambda r: -r["ms"]):
+            per = r["ms"] / r["launches"]
+            gbs = STAGE_BYTES.get(r["stage"], 0.0) * r["units"] / r["launches"] / (per * 1e-3) / 1e9
+            print(f"  {r['stage']:16s} L{r['level']} launches={r['launches']:4d} total={r['ms']:9.3f} ms "
+                  f"avg={per:8.4f} ms  alg={gbs:8.1f} GB/s", file=sys.stderr)
     pairs_total = B * world * args.steps
     value = pairs_total / elapsed
     alg_pair = algorithmic_bytes_per_pair(W, H, plan, PARAMS["iterations"])

@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libofarn.so")
-SOURCES = ["kernels_generic.hip", "ofarn_api.hip"]
-HEADERS = [os.path.join(CSRC, "ofarn_internal.h"), os.path.join(ROOT, "include", "ofarn.h")]
+SOURCES = ["kernels_generic.hip", "kernels_fast.hip", "ofarn_api.hip"]
+HEADERS = [os.path.join(CSRC, "ofarn_internal.h"), os.path.join(CSRC, "farneback_device.h"), os.path.join(ROOT, "include", "ofarn.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-result"]
 

@@ -1,0 +1,358 @@
+// kernels_fast.hip -- fused kernels the default parameter set dispatches to.
+//
+// k_flow_iter: one Farneback iteration = FarnebackUpdateMatrices + FarnebackUpdateFlow_Blur fused
+// (stages C + D; with MODE 1 also stage E, the flow upsample).  M never goes to HBM.
+//
+//   * A block of 256 threads owns a strip of 256-2m columns (m = winsize/2) plus an m-column halo
+//     on each side, one thread per column, and MARCHES down `strip_h` rows.
+//   * Each thread computes G11,G12,G22,h1,h2 for its column at row y+m (bilinear gather of R1,
+//     combine with R0, border damping: update_matrices_px) and keeps the last 2m+1 rows of its
+//     column in a register window -- the box filter's vertical pass never touches LDS.
+//   * The column sums (double) of one row are exchanged through a double-buffered LDS line; the
+//     horizontal pass, the 1/winsize^2 scale and the regularised 2x2 solve follow, then the
+//     (dx, dy) row is written (coalesced float2).
+//   * flow is read from flow_in and written to flow_out (ping-pong): neighbouring strips read
+//     each other's halo columns, so the update cannot be in place.
+//
+// Summation order is the oracle's OFO_BOX_DIRECT order (rows y-m..y+m top to bottom in double,
+// then columns x-m..x+m left to right in double), so results equal the unfused generic kernels
+// and the CPU oracle bit for bit.
+//
+// Roofline: HBM-bound by design: per pixel and iteration it reads flow 8 B + R0 20 B + R1 20 B
+// (gathered, mostly sequential) and writes 8 B, x (256/(256-2m)) x ((strip_h+2m)/strip_h) halo
+// re-reads that L2 mostly absorbs; ~150 f64 adds per pixel keep the f64 pipe about half busy.
+#include "farneback_device.h"
+#include "ofarn_internal.h"
+
+namespace ofarn {
+
+constexpr int FI_THREADS = 256;
+
+struct UpsampleArgs {
+    const float2 *coarse;   // [P][ch][cw]
+    int cw, ch;
+    const int *xofs;
+    const float *xa;
+    const int *yofs;
+    const float *ya;
+    float mul;
+};
+
+template <int M_, int MODE>   // MODE 0: flow_in == 0;  1: flow_in = upsample(coarse)*mul;  2: flow_in from HBM
+__global__ __launch_bounds__(FI_THREADS) void k_flow_iter(const float *__restrict__ R, int fstep,
+                                                          const float2 *__restrict__ flow_in,
+                                                          float2 *__restrict__ flow_out, int w, int h,
+                                                          int strip_h, double scale, UpsampleArgs up)
+{
+    constexpr int TAPS = 2 * M_ + 1;
+    constexpr int OUTW = FI_THREADS - 2 * M_;
+    __shared__ double sV[2][5][FI_THREADS];
+
+    const int tid = threadIdx.x;
+    const int x = blockIdx.x * OUTW - M_ + tid;
+    const int xc = clampi(x, 0, w - 1);
+    const int y0 = blockIdx.y * strip_h;
+    const int y1 = min(y0 + strip_h, h);
+    const size_t npx = (size_t)w * h;
+    const size_t p = blockIdx.z;
+    const float *R0 = R + p * fstep * 5 * npx;
+    const float *R1 = R0 + 5 * npx;
+    const float2 *fin = MODE == 2 ? flow_in + p * npx : nullptr;
+    float2 *fout = flow_out + p * npx;
+
+    // per-thread constants of the on-the-fly upsample (resize INTER_LINEAR, horizontal weights)
+    int usx = 0, usx1 = 0;
+    float ua0 = 0.f, ua1 = 0.f;
+    const float2 *coarse = nullptr;
+    if (MODE == 1) {
+        usx = up.xofs[xc];
+        usx1 = usx + 1 < up.cw ? usx + 1 : up.cw - 1;
+        ua1 = up.xa[xc];
+        ua0 = 1.f - ua1;
+        coarse = up.coarse + p * (size_t)up.cw * up.ch;
+    }
+
+    auto matrices_at = [&](int yy, float m[5]) {
+        float dx = 0.f, dy = 0.f;
+        if (MODE == 2) {
+            const float2 d = fin[(size_t)yy * w + xc];
+            dx = d.x; dy = d.y;
+        } else if (MODE == 1) {
+            const int sy = up.yofs[yy];
+            const int sy1 = sy + 1 < up.ch ? sy + 1 : up.ch - 1;
+            const float b1 = up.ya[yy], b0 = 1.f - b1;
+            const float2 p00 = coarse[(size_t)sy * up.cw + usx], p01 = coarse[(size_t)sy * up.cw + usx1];
+            const float2 p10 = coarse[(size_t)sy1 * up.cw + usx], p11 = coarse[(size_t)sy1 * up.cw + usx1];
+            const float r0x = p00.x * ua0 + p01.x * ua1, r0y = p00.y * ua0 + p01.y * ua1;
+            const float r1x = p10.x * ua0 + p11.x * ua1, r1y = p10.y * ua0 + p11.y * ua1;
+            dx = (r0x * b0 + r1x * b1) * up.mul;
+            dy = (r0y * b0 + r1y * b1) * up.mul;
+        }
+        update_matrices_px(R0, R1, npx, w, h, xc, yy, dx, dy, m);
+    };
+
+    // register window: win[c][j] = M_c at row (y - M_ + j) of this thread's column
+    float win[5][TAPS];
+    {
+        float m[5];
+        int last = -1;
+        for (int j = 1; j < TAPS; j++) {      // rows y0-M_ .. y0+M_-1 go to slots 1..TAPS-1
+            const int yy = clampi(y0 - M_ + (j - 1), 0, h - 1);
+            if (yy != last) { matrices_at(yy, m); last = yy; }
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                // static indexing only: place via unrolled select
+#pragma unroll
+                for (int q = 1; q < TAPS; q++) if (q == j) win[c][q] = m[c];
+            }
+        }
+    }
+
+    int buf = 0;
+    for (int y = y0; y < y1; y++) {
+        float m[5];
+        matrices_at(clampi(y + M_, 0, h - 1), m);
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+#pragma unroll
+            for (int j = 0; j < TAPS - 1; j++) win[c][j] = win[c][j + 1];
+            win[c][TAPS - 1] = m[c];
+            double s = (double)win[c][0];
+#pragma unroll
+            for (int j = 1; j < TAPS; j++) s += (double)win[c][j];
+            sV[buf][c][tid] = s;
+        }
+        __syncthreads();
+        if (tid >= M_ && tid < FI_THREADS - M_ && x < w) {
+            double g[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const double *v = &sV[buf][c][tid - M_];
+                double s = v[0];
+#pragma unroll
+                for (int i = 1; i < TAPS; i++) s += v[i];
+                g[c] = s * scale;
+            }
+            const double idet = 1. / (g[0] * g[2] - g[1] * g[1] + 1e-3);
+            float2 o;
+            o.x = (float)((g[0] * g[4] - g[1] * g[3]) * idet);
+            o.y = (float)((g[2] * g[3] - g[1] * g[4]) * idet);
+            fout[(size_t)y * w + x] = o;
+        }
+        buf ^= 1;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// k_polyexp_march: FarnebackPolyExp (stage B) with compile-time radius N, marching layout.
+//   SRC 0: reads the float level image I[h][w] (levels >= 1).
+//   SRC 1: level 0 fused with stage A: reads the uint8 frame and applies the 3-tap Gaussian
+//          ([1/4,1/2,1/4], BORDER_REFLECT_101, row pass then column pass) on the fly -- at scale 1
+//          resize() is the identity, so the level image never exists in HBM.
+// One thread per column (256-2N outputs per block row), marching down strip_h rows with the last
+// 2N+1 level-image values of its column in registers: the float32 vertical pass is private, the
+// (r0, r1, r2) line is exchanged through a double-buffered LDS line, the horizontal pass
+// accumulates in double in optflowgf.cpp's order.  Bit-identical to k_polyexp / the oracle.
+// ---------------------------------------------------------------------------------------------
+template <int N, int SRC>
+__global__ __launch_bounds__(FI_THREADS) void k_polyexp_march(const void *__restrict__ src, size_t src_stride,
+                                                              float *__restrict__ R, int w, int h, int strip_h,
+                                                              PolyCoef c, float k0, float k1, float k2)
+{
+    constexpr int TAPS = 2 * N + 1;
+    constexpr int OUTW = FI_THREADS - 2 * N;
+    __shared__ float sRow[2][3][FI_THREADS];
+
+    const int tid = threadIdx.x;
+    const int x = blockIdx.x * OUTW - N + tid;
+    const int xc = clampi(x, 0, w - 1);
+    const int y0 = blockIdx.y * strip_h;
+    const int y1 = min(y0 + strip_h, h);
+    const size_t npx = (size_t)w * h;
+    const float *img = SRC == 0 ? reinterpret_cast<const float *>(src) + (size_t)blockIdx.z * src_stride : nullptr;
+    const uint8_t *frm = SRC == 1 ? reinterpret_cast<const uint8_t *>(src) + (size_t)blockIdx.z * src_stride : nullptr;
+    float *out = R + (size_t)blockIdx.z * 5 * npx;
+
+    // level-0 source: 3-tap blur state for this column (row pass of rows yy-1, yy, yy+1)
+    const int xl = reflect101(xc - 1, w), xr = reflect101(xc + 1, w);
+    float rpm = 0.f, rpc = 0.f, rpp = 0.f, icur = 0.f;
+    int ry = -0x40000000;
+    auto rowpass = [&](int row) {
+        const uint8_t *f = frm + (size_t)row * w;
+        float s = k0 * (float)f[xl];
+        s = s + k1 * (float)f[xc];
+        s = s + k2 * (float)f[xr];
+        return s;
+    };
+    auto level_at = [&](int yy) -> float {   // yy in [0, h-1], non-decreasing from call to call
+        if (SRC == 0) return img[(size_t)yy * w + xc];
+        if (yy == ry) return icur;
+        if (yy == ry + 1) { rpm = rpc; rpc = rpp; }
+        else { rpm = rowpass(reflect101(yy - 1, h)); rpc = rowpass(yy); }
+        rpp = rowpass(reflect101(yy + 1, h));
+        ry = yy;
+        icur = k1 * rpc + k2 * (rpp + rpm);
+        return icur;
+    };
+
+    float win[TAPS];
+    for (int j = 1; j < TAPS; j++) {
+        const float v = level_at(clampi(y0 - N + (j - 1), 0, h - 1));
+#pragma unroll
+        for (int q = 1; q < TAPS; q++) if (q == j) win[q] = v;
+    }
+
+    int buf = 0;
+    for (int y = y0; y < y1; y++) {
+        const float v = level_at(clampi(y + N, 0, h - 1));
+#pragma unroll
+        for (int j = 0; j < TAPS - 1; j++) win[j] = win[j + 1];
+        win[TAPS - 1] = v;
+        float r0 = win[N] * c.g[0], r1 = 0.f, r2 = 0.f;
+#pragma unroll
+        for (int k = 1; k <= N; k++) {
+            const float a = win[N - k], b = win[N + k];
+            const float pp = a + b;
+            r0 = r0 + c.g[k] * pp;
+            r1 = r1 + c.xg[k] * (b - a);
+            r2 = r2 + c.xxg[k] * pp;
+        }
+        sRow[buf][0][tid] = r0;
+        sRow[buf][1][tid] = r1;
+        sRow[buf][2][tid] = r2;
+        __syncthreads();
+        if (tid >= N && tid < FI_THREADS - N && x < w) {
+            const float *p0 = &sRow[buf][0][tid], *p1 = &sRow[buf][1][tid], *p2 = &sRow[buf][2][tid];
+            const float g0 = c.g[0];
+            double b1 = p0[0] * g0, b2 = 0, b3 = p1[0] * g0, b4 = 0, b5 = p2[0] * g0, b6 = 0;
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+                const float gk = c.g[k], xgk = c.xg[k], xxgk = c.xxg[k];
+                const double tg = p0[k] + p0[-k];
+                b1 += tg * gk;
+                b4 += tg * xxgk;
+                b2 += (p0[k] - p0[-k]) * xgk;
+                b3 += (p1[k] + p1[-k]) * gk;
+                b6 += (p1[k] - p1[-k]) * xgk;
+                b5 += (p2[k] + p2[-k]) * gk;
+            }
+            const size_t o = (size_t)y * w + x;
+            out[o] = (float)(b3 * c.ig11);
+            out[npx + o] = (float)(b2 * c.ig11);
+            out[2 * npx + o] = (float)(b1 * c.ig03 + b5 * c.ig33);
+            out[3 * npx + o] = (float)(b1 * c.ig03 + b4 * c.ig33);
+            out[4 * npx + o] = (float)(b6 * c.ig55);
+        }
+        buf ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_level_hpass_lds: stage A pass 1 for levels >= 1 (same arithmetic as k_level_hpass).
+// One block per frame row: the uint8 row is converted to float once and staged in LDS together
+// with its reflect-101 border, so the ksize-tap loop has no border logic and no byte loads.
+// LDS index i is skewed to i + (i >> 5): level columns are 2^k source pixels apart, which would
+// put every lane on one bank; with the skew any power-of-two stride is conflict free.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int skew(int i) { return i + (i >> 5); }
+
+__global__ __launch_bounds__(256) void k_level_hpass_lds(const uint8_t *__restrict__ frames, size_t frame_stride,
+                                                          int W, int H, const float *__restrict__ kern, int ksize,
+                                                          const int *__restrict__ xofs, int dw,
+                                                          float2 *__restrict__ tmp)
+{
+    extern __shared__ float srow[];   // skew(W + 2r) floats, then ksize kernel taps
+    const int r = ksize >> 1;
+    const int y = blockIdx.y;
+    const uint8_t *row = frames + (size_t)blockIdx.z * frame_stride + (size_t)y * W;
+    const int tid = threadIdx.x;
+    const int ext = W + 2 * r;
+    float *sk = srow + skew(ext) + 1;
+    for (int i = tid; i < ext; i += 256) srow[skew(i)] = (float)row[reflect101(i - r, W)];
+    for (int i = tid; i < ksize; i += 256) sk[i] = kern[i];
+    __syncthreads();
+    float2 *dst = tmp + ((size_t)blockIdx.z * H + y) * dw;
+    for (int dx = tid; dx < dw; dx += 256) {
+        const int sx = xofs[dx];
+        const int sx1 = sx + 1 < W ? sx + 1 : W - 1;
+        // source column c sits at extended index c + r; tap t reads c - r + t -> extended c + t
+        float s0 = sk[0] * srow[skew(sx)];
+        float s1 = sk[0] * srow[skew(sx1)];
+        for (int t = 1; t < ksize; t++) {
+            const float f = sk[t];
+            s0 = s0 + f * srow[skew(sx + t)];
+            s1 = s1 + f * srow[skew(sx1 + t)];
+        }
+        dst[dx] = make_float2(s0, s1);
+    }
+}
+
+static inline unsigned cdivu(int a, int b) { return (unsigned)((a + b - 1) / b); }
+
+bool flow_iter_supported(int winsize) { return winsize / 2 == 7; }
+
+// mode 0: zero input flow; 1: upsample from coarse (up_* valid); 2: read flow_in.
+void launch_flow_iter(hipStream_t s, const float *R, int fstep, const float *flow_in, float *flow_out, int w,
+                      int h, int npairs, int winsize, int mode, const float *coarse, int cw, int ch,
+                      const int *d_xofs, const float *d_xa, const int *d_yofs, const float *d_ya, float mul)
+{
+    constexpr int M_ = 7;
+    constexpr int OUTW = FI_THREADS - 2 * M_;
+    int nstrips = (h + 64) / 128;
+    if (nstrips < 1) nstrips = 1;
+    const int strip_h = (h + nstrips - 1) / nstrips;
+    dim3 grid(cdivu(w, OUTW), cdivu(h, strip_h), npairs);
+    const double scale = 1. / ((double)winsize * winsize);
+    UpsampleArgs up{reinterpret_cast<const float2 *>(coarse), cw, ch, d_xofs, d_xa, d_yofs, d_ya, mul};
+    const float2 *fin = reinterpret_cast<const float2 *>(flow_in);
+    float2 *fout = reinterpret_cast<float2 *>(flow_out);
+    if (mode == 0)
+        hipLaunchKernelGGL((k_flow_iter<M_, 0>), grid, dim3(FI_THREADS), 0, s, R, fstep, fin, fout, w, h, strip_h, scale, up);
+    else if (mode == 1)
+        hipLaunchKernelGGL((k_flow_iter<M_, 1>), grid, dim3(FI_THREADS), 0, s, R, fstep, fin, fout, w, h, strip_h, scale, up);
+    else
+        hipLaunchKernelGGL((k_flow_iter<M_, 2>), grid, dim3(FI_THREADS), 0, s, R, fstep, fin, fout, w, h, strip_h, scale, up);
+}
+
+}  // namespace ofarn
+
+namespace ofarn {
+
+static inline int pick_strip(int h)
+{
+    int nstrips = (h + 64) / 128;
+    if (nstrips < 1) nstrips = 1;
+    return (h + nstrips - 1) / nstrips;
+}
+
+bool polyexp_march_supported(int poly_n) { return poly_n == 5; }
+
+// src_is_u8 = 1: level 0, src = uint8 frames (stride in bytes = elements); else float level images.
+void launch_polyexp_march(hipStream_t s, const void *src, size_t src_stride, int src_is_u8, float *R, int w, int h,
+                          int nframes, const PolyCoef &c, const float *blur3)
+{
+    constexpr int N = 5;
+    constexpr int OUTW = FI_THREADS - 2 * N;
+    const int strip_h = pick_strip(h);
+    dim3 grid(cdivu(w, OUTW), cdivu(h, strip_h), nframes);
+    if (src_is_u8)
+        hipLaunchKernelGGL((k_polyexp_march<N, 1>), grid, dim3(FI_THREADS), 0, s, src, src_stride, R, w, h, strip_h, c,
+                           blur3[0], blur3[1], blur3[2]);
+    else
+        hipLaunchKernelGGL((k_polyexp_march<N, 0>), grid, dim3(FI_THREADS), 0, s, src, src_stride, R, w, h, strip_h, c,
+                           0.f, 0.f, 0.f);
+}
+
+void launch_level_hpass_lds(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
+                            const float *d_kern, int ksize, const int *d_xofs, int dw, float *tmp)
+{
+    const int r = ksize >> 1;
+    const int ext = W + 2 * r;
+    const size_t lds = sizeof(float) * (size_t)(ext + (ext >> 5) + 2 + ksize);
+    dim3 grid(1, H, nframes);
+    hipLaunchKernelGGL(k_level_hpass_lds, grid, dim3(256), lds, s, frames, frame_stride, W, H, d_kern, ksize, d_xofs,
+                       dw, reinterpret_cast<float2 *>(tmp));
+}
+
+}  // namespace ofarn

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -145,6 +146,7 @@ struct Level {
     double sigma = 0;
     // device tables
     float *d_kern = nullptr;
+    float h_kern3[3] = {0, 0, 0};   // host copy of the taps when ksize == 3
     int *d_xofs = nullptr, *d_yofs = nullptr;        // image resize W->w, H->h
     float *d_xa = nullptr, *d_ya = nullptr;
     int *d_fxofs = nullptr, *d_fyofs = nullptr;      // flow resize (k+1) -> k
@@ -229,6 +231,7 @@ struct ofarn_ctx {
     // per-kernel profiling (ofarn_profile_*): hipEvent pairs around each launch, on the launch stream
     struct ProfRec { int stage, level; double units; hipEvent_t a, b; };
     bool prof_on = false;
+    bool force_generic = false;   // OFARN_FORCE_GENERIC=1 or ofarn_set_option: use the unfused kernels only
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> prof_free;
     struct ProfAcc { int launches = 0; double ms = 0, units = 0; };
@@ -269,7 +272,11 @@ int make_plan(ofarn_ctx *c, int w, int h)
         level_geom(w, h, c->prm.pyr_scale, k, L.w, L.h, L.sigma, L.ksize);
         if (L.w < 1 || L.h < 1) return fail(OFARN_E_INVALID, "level %d is empty", k);
         int rc;
-        if ((rc = upload(c, gaussian_kernel(L.ksize, L.sigma), &L.d_kern))) return rc;
+        {
+            const std::vector<float> kv = gaussian_kernel(L.ksize, L.sigma);
+            if (L.ksize == 3) for (int i = 0; i < 3; i++) L.h_kern3[i] = kv[i];
+            if ((rc = upload(c, kv, &L.d_kern))) return rc;
+        }
         std::vector<int> ofs;
         std::vector<float> al;
         resize_tables(w, L.w, ofs, al);
@@ -334,27 +341,61 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
     const int nlev = (int)c->lv.size() - 1;
     float *prev = nullptr;
     int pw = 0, ph = 0;
-    float *bufs[2] = {c->flowA, c->flowB};
-    int flip = 0;
+    const bool fused = !c->force_generic && c->prm.iterations >= 1 && flow_iter_supported(c->prm.winsize);
     for (int k = nlev; k >= 0; k--) {
         const Level &L = c->lv[k];
-        float *flow = (k == 0 && d_flow) ? d_flow : bufs[flip];
-        flip ^= 1;
         const size_t npx = (size_t)L.w * L.h;
         const double upx = (double)npx * npairs, ufr = (double)npx * nframes;
+        const float mul = (float)(1. / c->prm.pyr_scale);
+        // stages A + B: level image and polynomial expansion of every frame of the wave
+        const bool march = !c->force_generic && polyexp_march_supported(c->prm.poly_n);
+        const bool lds_ok = (size_t)(w + 2 * (L.ksize / 2)) * 4 * 33 / 32 + 4 * (size_t)L.ksize + 64 <= 60 * 1024;
+        if (march && L.w == w && L.h == h && L.ksize == 3) {
+            // scale 1: 3-tap blur fused into the polynomial expansion, frames read directly
+            timed(c, s, OFARN_STAGE_POLYEXP, k, ufr, [&] {
+                launch_polyexp_march(s, d_frames, fsz, 1, c->R, L.w, L.h, nframes, c->poly, L.h_kern3);
+            });
+        } else {
+            timed(c, s, OFARN_STAGE_LEVEL_H, k, ufr, [&] {
+                if (!c->force_generic && lds_ok)
+                    launch_level_hpass_lds(s, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, c->tmp);
+                else
+                    launch_level_hpass(s, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, c->tmp);
+            });
+            timed(c, s, OFARN_STAGE_LEVEL_V, k, ufr, [&] {
+                launch_level_vpass(s, c->tmp, h, L.w, L.h, nframes, L.d_kern, L.ksize, L.d_xa, L.d_yofs, L.d_ya, c->I);
+            });
+            timed(c, s, OFARN_STAGE_POLYEXP, k, ufr, [&] {
+                if (march) launch_polyexp_march(s, c->I, npx, 0, c->R, L.w, L.h, nframes, c->poly, L.h_kern3);
+                else launch_polyexp(s, c->I, c->R, L.w, L.h, nframes, c->poly);
+            });
+        }
+        if (fused) {
+            // stages (E +) C + D fused per iteration; flow ping-pongs between two buffers, the last
+            // iteration of level 0 writes the caller's buffer.  The coarse flow is only read by
+            // iteration 0, so its buffer is free again from iteration 1 on.
+            const float *cur = nullptr;
+            for (int i = 0; i < c->prm.iterations; i++) {
+                const float *busy = i == 0 ? prev : cur;
+                float *out = (i == c->prm.iterations - 1 && k == 0 && d_flow) ? d_flow
+                             : (busy == c->flowA ? c->flowB : c->flowA);
+                const int mode = i == 0 ? (prev ? 1 : 0) : 2;
+                timed(c, s, OFARN_STAGE_FLOW_ITER, k, upx, [&] {
+                    launch_flow_iter(s, c->R, fstep, cur, out, L.w, L.h, npairs, c->prm.winsize, mode, prev, pw, ph,
+                                     L.d_fxofs, L.d_fxa, L.d_fyofs, L.d_fya, mul);
+                });
+                cur = out;
+            }
+            prev = const_cast<float *>(cur); pw = L.w; ph = L.h;
+            continue;
+        }
+        float *flow = (k == 0 && d_flow) ? d_flow : (prev == c->flowA ? c->flowB : c->flowA);
         if (!prev) HIP_TRY(hipMemsetAsync(flow, 0, npx * 2 * sizeof(float) * npairs, s));
         else
             timed(c, s, OFARN_STAGE_UPSAMPLE, k, upx, [&] {
                 launch_flow_upsample(s, prev, pw, ph, flow, L.w, L.h, npairs, L.d_fxofs, L.d_fxa, L.d_fyofs,
-                                     L.d_fya, (float)(1. / c->prm.pyr_scale));
+                                     L.d_fya, mul);
             });
-        timed(c, s, OFARN_STAGE_LEVEL_H, k, ufr, [&] {
-            launch_level_hpass(s, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, c->tmp);
-        });
-        timed(c, s, OFARN_STAGE_LEVEL_V, k, ufr, [&] {
-            launch_level_vpass(s, c->tmp, h, L.w, L.h, nframes, L.d_kern, L.ksize, L.d_xa, L.d_yofs, L.d_ya, c->I);
-        });
-        timed(c, s, OFARN_STAGE_POLYEXP, k, ufr, [&] { launch_polyexp(s, c->I, c->R, L.w, L.h, nframes, c->poly); });
         timed(c, s, OFARN_STAGE_MATRICES, k, upx, [&] { launch_update_matrices(s, c->R, fstep, flow, c->M, L.w, L.h, npairs); });
         for (int i = 0; i < c->prm.iterations; i++) {
             timed(c, s, OFARN_STAGE_BLUR_SOLVE, k, upx, [&] { launch_blur_solve(s, c->M, flow, L.w, L.h, npairs, c->prm.winsize); });
@@ -439,6 +480,10 @@ int ofarn_create(const ofarn_params *params, int device, int max_w, int max_h, i
     c->prm = *params;
     c->device = device;
     c->max_w = max_w; c->max_h = max_h; c->max_batch = max_batch;
+    {
+        const char *e = getenv("OFARN_FORCE_GENERIC");
+        c->force_generic = e && e[0] == '1';
+    }
     if (!poly_prepare(params->poly_n, params->poly_sigma, c->poly)) {
         delete c;
         return fail(OFARN_E_INVALID, "poly_n out of range");
@@ -707,7 +752,11 @@ int ofarn_stage_level_image(ofarn_ctx *c, const uint8_t *h_img, int w, int h, in
     const size_t fsz = (size_t)w * h;
     if ((rc = ensure_staging(c, fsz, 0, 0))) return rc;
     HIP_TRY(hipMemcpyAsync(c->st_frames, h_img, fsz, hipMemcpyHostToDevice, c->stream));
-    launch_level_hpass(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->tmp);
+    const bool lds_ok = (size_t)(w + 2 * (L.ksize / 2)) * 4 * 33 / 32 + 4 * (size_t)L.ksize + 64 <= 60 * 1024;
+    if (!c->force_generic && lds_ok)
+        launch_level_hpass_lds(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->tmp);
+    else
+        launch_level_hpass(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->tmp);
     launch_level_vpass(c->stream, c->tmp, h, L.w, L.h, 1, L.d_kern, L.ksize, L.d_xa, L.d_yofs, L.d_ya, c->I);
     HIP_TRY(hipMemcpyAsync(h_out, c->I, (size_t)L.w * L.h * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -722,7 +771,11 @@ int ofarn_stage_polyexp(ofarn_ctx *c, const float *h_img, int w, int h, float *h
     HIP_TRY(hipSetDevice(c->device));
     const size_t npx = (size_t)w * h;
     HIP_TRY(hipMemcpyAsync(c->I, h_img, npx * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    launch_polyexp(c->stream, c->I, c->R, w, h, 1, c->poly);
+    if (!c->force_generic && polyexp_march_supported(c->prm.poly_n)) {
+        const float none[3] = {0, 0, 0};
+        launch_polyexp_march(c->stream, c->I, npx, 0, c->R, w, h, 1, c->poly, none);
+    } else
+        launch_polyexp(c->stream, c->I, c->R, w, h, 1, c->poly);
     HIP_TRY(hipMemcpyAsync(h_R, c->R, npx * 5 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return OFARN_OK;

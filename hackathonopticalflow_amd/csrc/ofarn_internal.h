@@ -48,6 +48,20 @@ void launch_update_matrices(hipStream_t s, const float *R, int fstep, const floa
 // Stage D: box average + 2x2 solve
 void launch_blur_solve(hipStream_t s, const float *M, float *flow, int w, int h, int npairs,
                        int winsize);
+// Stages (E+)C+D fused (kernels_fast.hip).  mode 0: zero input flow; 1: input flow is
+// upsample(coarse)*mul computed on the fly; 2: input flow read from flow_in.  flow_out != flow_in.
+bool flow_iter_supported(int winsize);
+void launch_flow_iter(hipStream_t s, const float *R, int fstep, const float *flow_in, float *flow_out, int w,
+                      int h, int npairs, int winsize, int mode, const float *coarse, int cw, int ch,
+                      const int *d_xofs, const float *d_xa, const int *d_yofs, const float *d_ya, float mul);
+// Stage B with compile-time radius, marching layout; with src_is_u8 the level-0 3-tap blur (stage A at
+// scale 1) is fused in and `src` are the uint8 frames.  blur3 = host pointer to the 3 kernel taps.
+bool polyexp_march_supported(int poly_n);
+void launch_polyexp_march(hipStream_t s, const void *src, size_t src_stride, int src_is_u8, float *R, int w, int h,
+                          int nframes, const PolyCoef &c, const float *blur3);
+// Stage A pass 1 with the frame row staged in LDS (levels >= 1).
+void launch_level_hpass_lds(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
+                            const float *d_kern, int ksize, const int *d_xofs, int dw, float *tmp);
 // Stage F: grid sample + vector filter + danger brightness.  d_pts int2[P] grid coordinates.
 int grid_filter_lds_bytes(int P);
 void launch_grid_filter(hipStream_t s, const float *flow, int w, int h, int npairs, const int *d_pts,

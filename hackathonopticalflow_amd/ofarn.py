@@ -285,14 +285,14 @@ class FarnebackEngine:
 
     # ------------------------------------------------------------------ per-kernel timing
     STAGES = ("level_hpass", "level_vpass", "polyexp", "flow_upsample", "update_matrices", "blur_solve",
-              "grid_filter")
+              "grid_filter", "flow_iter")
 
     def profile_enable(self, on=True):
         _check(self._lib.ofarn_profile_enable(self._h, int(bool(on))))
 
     def profile_read(self):
         """[{stage, level, launches, ms, units}] since the last read (waits for the recorded events)."""
-        cap = 7 * 32
+        cap = 8 * 32
         st, lv, ln = (C.c_int * cap)(), (C.c_int * cap)(), (C.c_int * cap)()
         ms, un = (C.c_double * cap)(), (C.c_double * cap)()
         n = self._lib.ofarn_profile_read(self._h, cap, st, lv, ln, ms, un)

@@ -120,7 +120,8 @@ double ofarn_last_device_ms(const ofarn_ctx *ctx);
 #define OFARN_STAGE_MATRICES 4    /* C: FarnebackUpdateMatrices                         */
 #define OFARN_STAGE_BLUR_SOLVE 5  /* D: FarnebackUpdateFlow_Blur                        */
 #define OFARN_STAGE_GRID_FILTER 6 /* F: grid sample + vector filter + V                 */
-#define OFARN_STAGE_COUNT 7
+#define OFARN_STAGE_FLOW_ITER 7   /* (E+)C+D fused: one Farneback iteration, M stays on chip */
+#define OFARN_STAGE_COUNT 8
 int ofarn_profile_enable(ofarn_ctx *ctx, int on);
 int ofarn_profile_read(ofarn_ctx *ctx, int cap, int *stage, int *level, int *launches, double *ms,
                        double *units);

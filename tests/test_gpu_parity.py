@@ -116,6 +116,36 @@ def test_pipeline_vs_oracle(H, oracle, w, h, seed, kw):
     assert e.mean() <= TOL_MEAN_EPE and e.max() <= TOL_MAX_EPE, (e.mean(), e.max())
 
 
+def test_stage_kernels_generic_variants(H, oracle, monkeypatch):
+    """The stage tests above run the specialised kernels where they exist (marching poly
+    expansion, LDS-staged row pass); this repeats two of them on the generic kernels."""
+    monkeypatch.setenv("OFARN_FORCE_GENERIC", "1")
+    rng = np.random.default_rng(1)
+    I = rng.uniform(0, 255, (83, 300)).astype(np.float32)
+    with H.FarnebackEngine(300, 83, 1) as eng:
+        np.testing.assert_array_equal(eng.stage_polyexp(I), planar(oracle.polyexp(I, 5, 1.2)))
+    img, _, _ = translated_pair(251, 333, 7)
+    with H.FarnebackEngine(333, 251, 1, levels=2) as eng:
+        for k, (lw, lh, ks, sg) in enumerate(H.level_plan(333, 251, levels=2)):
+            np.testing.assert_array_equal(eng.stage_level_image(img, k), oracle.level_image(img, ks, sg, lw, lh))
+
+
+def test_generic_and_fused_paths_agree(H, oracle, monkeypatch):
+    """winsize 15 dispatches to the fused marching kernel; OFARN_FORCE_GENERIC=1 keeps the unfused
+    generic kernels.  Both must equal the oracle bit for bit (multi-strip, multi-block sizes)."""
+    prev, nxt, _ = translated_pair(300, 520, 41, max_shift=6)
+    ref = oracle.farneback(prev, nxt, levels=2, box_mode=oracle.BOX_DIRECT)
+    with H.FarnebackEngine(520, 300, 1, levels=2) as eng:
+        np.testing.assert_array_equal(eng.calc(prev, nxt), ref)
+    monkeypatch.setenv("OFARN_FORCE_GENERIC", "1")
+    with H.FarnebackEngine(520, 300, 1, levels=2) as eng:
+        np.testing.assert_array_equal(eng.calc(prev, nxt), ref)
+    monkeypatch.delenv("OFARN_FORCE_GENERIC")
+    for iters in (1, 2, 4):
+        ref = oracle.farneback(prev, nxt, levels=1, iterations=iters, box_mode=oracle.BOX_DIRECT)
+        np.testing.assert_array_equal(H.calculate_optical_flow(prev, nxt, levels=1, iterations=iters), ref)
+
+
 def test_pipeline_1080p_L5_config2(H, oracle):
     """BASELINE config 2: one 1920x1080 pair, levels=5, iterations=3, seed 2001."""
     prev, nxt, (tx, ty) = translated_pair(1080, 1920, 2001)
