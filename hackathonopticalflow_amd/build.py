@@ -29,25 +29,37 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str | None = None) -> str:
+    """Compiles the sources and links libofarn.so.  `extra_flags` / `out` build an experimental
+    variant (e.g. -DOFARN_ABLATE=1 for a timing-only ablation) next to the product library; such a
+    variant is selected at run time with the OFARN_LIB environment variable."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    lib = LIB if out is None else os.path.join(HERE, out)
+    tag = "" if out is None else "." + os.path.splitext(out)[0]
+    force = force or bool(extra_flags)
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
+        o = os.path.join(CSRC, src.rsplit(".", 1)[0] + tag + ".o")
         objs.append(o)
         if force or _stale(o, [s] + HEADERS + [os.path.abspath(__file__)]):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs
+    if force or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    args = sys.argv[1:]
+    out = None
+    if "--out" in args:
+        i = args.index("--out")
+        out = args[i + 1]
+        del args[i:i + 2]
+    print(build(force="--force" in args, verbose=True, extra_flags=[a for a in args if a.startswith("-D")], out=out))

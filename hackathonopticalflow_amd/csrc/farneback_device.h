@@ -59,4 +59,113 @@ __device__ __forceinline__ void update_matrices_px(const float *__restrict__ R0,
     out[4] = r6 * r2 + r5 * r3;
 }
 
+
+// Loads/stores at (uniform base pointer + 32-bit byte offset): lets the compiler use the
+// scalar-base addressing form (one VGPR per address).  Byte offsets must stay below 4 GiB per plane.
+__device__ __forceinline__ float ldg_f32(const float *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ float2 ldg_f2(const float2 *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ void stg_f2(float2 *base, unsigned byte_off, float2 v)
+{
+    *reinterpret_cast<float2 *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
+
+// ---- FarnebackUpdateMatrices split in two for software pipelining -------------------------------
+// gather_issue() only computes addresses and issues the loads (flow-dependent bilinear taps of R1
+// plus R0 at the pixel); matrices_finish() does the arithmetic.  Together they perform exactly the
+// operations of update_matrices_px, in the same order.
+struct GatherRaw {
+    float dx, dy, fx, fy;
+    float r0[5];
+    float t00[5], t01[5], t10[5], t11[5];
+    int inb;
+};
+
+__device__ __forceinline__ void gather_issue(const float *__restrict__ R0, const float *__restrict__ R1, size_t npx,
+                                             int w, int h, int x, int y, float dx, float dy, GatherRaw &g)
+{
+    float fx = (float)x + dx, fy = (float)y + dy;
+    const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    fx -= (float)x1; fy -= (float)y1;
+    g.dx = dx; g.dy = dy; g.fx = fx; g.fy = fy;
+    // 32-bit element offsets on uniform (scalar) plane bases: one VGPR per address instead of two
+    const unsigned o = (unsigned)y * (unsigned)w + (unsigned)x;
+#pragma unroll
+#if defined(OFARN_ABLATE) && OFARN_ABLATE == 6   /* no R loads at all */
+    for (int c = 0; c < 5; c++) g.r0[c] = dx * (float)(c + 1) + fy;
+#else
+    for (int c = 0; c < 5; c++) g.r0[c] = ldg_f32(R0 + c * npx, o * 4u);
+#endif
+    g.inb = ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) ? 1 : 0;
+    // out-of-range taps are never used; read a valid address instead so the loads stay unconditional
+    const unsigned q = g.inb ? (unsigned)y1 * (unsigned)w + (unsigned)x1 : 0u;
+    const unsigned q01 = g.inb ? q + 1u : 0u, q10 = g.inb ? q + (unsigned)w : 0u, q11 = g.inb ? q + (unsigned)w + 1u : 0u;
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const float *p = R1 + c * npx;
+#if defined(OFARN_ABLATE) && (OFARN_ABLATE == 1 || OFARN_ABLATE == 6)
+        (void)p; (void)q01; (void)q10; (void)q11;
+        g.t00[c] = g.r0[c]; g.t01[c] = g.r0[c]; g.t10[c] = g.r0[c]; g.t11[c] = g.r0[c];
+#elif defined(OFARN_ABLATE) && OFARN_ABLATE == 4   /* taps at the pixel itself: same load count, no gather */
+        g.t00[c] = ldg_f32(p, o * 4u); g.t01[c] = ldg_f32(p, o * 4u + 4u);
+        g.t10[c] = ldg_f32(p, (o + (unsigned)w) * 4u); g.t11[c] = ldg_f32(p, (o + (unsigned)w) * 4u + 4u);
+#elif defined(OFARN_ABLATE) && OFARN_ABLATE == 5   /* half the tap loads */
+        g.t00[c] = ldg_f32(p, q * 4u); g.t01[c] = g.t00[c];
+        g.t10[c] = ldg_f32(p, q10 * 4u); g.t11[c] = g.t10[c];
+#else
+        g.t00[c] = ldg_f32(p, q * 4u); g.t01[c] = ldg_f32(p, q01 * 4u);
+        g.t10[c] = ldg_f32(p, q10 * 4u); g.t11[c] = ldg_f32(p, q11 * 4u);
+#endif
+    }
+}
+
+// Branch-free: a divergent branch here makes the compiler drain every outstanding load at the
+// join (s_waitcnt vmcnt(0)), which would also wait for the NEXT rows' prefetched gathers.  The
+// selects and the multiplication by an interior scale of exactly 1.0f leave every bit unchanged.
+__device__ __forceinline__ float border_factor(int i) { return i < 2 ? 0.14f : 0.4472f; }   // BORDER table
+
+__device__ __forceinline__ void matrices_finish(const GatherRaw &g, int w, int h, int x, int y, float out[5])
+{
+    const float dx = g.dx, dy = g.dy, fx = g.fx, fy = g.fy;
+    const bool inb = g.inb != 0;
+    const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+    float r2 = a00 * g.t00[0] + a01 * g.t01[0] + a10 * g.t10[0] + a11 * g.t11[0];
+    float r3 = a00 * g.t00[1] + a01 * g.t01[1] + a10 * g.t10[1] + a11 * g.t11[1];
+    float r4 = a00 * g.t00[2] + a01 * g.t01[2] + a10 * g.t10[2] + a11 * g.t11[2];
+    float r5 = a00 * g.t00[3] + a01 * g.t01[3] + a10 * g.t10[3] + a11 * g.t11[3];
+    float r6 = a00 * g.t00[4] + a01 * g.t01[4] + a10 * g.t10[4] + a11 * g.t11[4];
+    r4 = (g.r0[2] + r4) * 0.5f;
+    r5 = (g.r0[3] + r5) * 0.5f;
+    r6 = (g.r0[4] + r6) * 0.25f;
+    r2 = inb ? r2 : 0.f;
+    r3 = inb ? r3 : 0.f;
+    r4 = inb ? r4 : g.r0[2];
+    r5 = inb ? r5 : g.r0[3];
+    r6 = inb ? r6 : g.r0[4] * 0.5f;
+    r2 = (g.r0[0] - r2) * 0.5f;
+    r3 = (g.r0[1] - r3) * 0.5f;
+    r2 = r2 + (r4 * dy + r6 * dx);
+    r3 = r3 + (r6 * dy + r5 * dx);
+    const float scale = (x < kBorder ? border_factor(x) : 1.f) * (x >= w - kBorder ? border_factor(w - x - 1) : 1.f) *
+                        (y < kBorder ? border_factor(y) : 1.f) * (y >= h - kBorder ? border_factor(h - y - 1) : 1.f);
+    r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    out[0] = r4 * r4 + r6 * r6;
+    out[1] = (r4 + r5) * r6;
+    out[2] = r5 * r5 + r6 * r6;
+    out[3] = r4 * r2 + r6 * r3;
+    out[4] = r6 * r2 + r5 * r3;
+}
+
+// Workgroup barrier that waits for LDS traffic only: __syncthreads() also drains vmcnt, which would
+// stall on the global loads deliberately left in flight for the next row.
+__device__ __forceinline__ void barrier_lds_only()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 }  // namespace ofarn

@@ -6,17 +6,17 @@
 //   * A block of 256 threads owns a strip of 256-2m columns (m = winsize/2) plus an m-column halo
 //     on each side, one thread per column, and MARCHES down `strip_h` rows.
 //   * Each thread computes G11,G12,G22,h1,h2 for its column at row y+m (bilinear gather of R1,
-//     combine with R0, border damping: update_matrices_px) and keeps the last 2m+1 rows of its
-//     column in a register window -- the box filter's vertical pass never touches LDS.
+//     combine with R0, border damping) and keeps the last 2m+1 rows of its column in registers:
+//     the box filter's vertical pass is 3 f64 ops per channel and never touches LDS.
 //   * The column sums (double) of one row are exchanged through a double-buffered LDS line; the
 //     horizontal pass, the 1/winsize^2 scale and the regularised 2x2 solve follow, then the
 //     (dx, dy) row is written (coalesced float2).
 //   * flow is read from flow_in and written to flow_out (ping-pong): neighbouring strips read
 //     each other's halo columns, so the update cannot be in place.
 //
-// Summation order is the oracle's OFO_BOX_DIRECT order (rows y-m..y+m top to bottom in double,
-// then columns x-m..x+m left to right in double), so results equal the unfused generic kernels
-// and the CPU oracle bit for bit.
+// Summation order is the oracle's OFO_BOX_BLOCKED order (column sums: running sums in double
+// restarted every 2m+1 rows; then columns x-m..x+m left to right in double), so results equal the
+// unfused generic kernels and the CPU oracle bit for bit.
 //
 // Roofline: HBM-bound by design: per pixel and iteration it reads flow 8 B + R0 20 B + R1 20 B
 // (gathered, mostly sequential) and writes 8 B, x (256/(256-2m)) x ((strip_h+2m)/strip_h) halo
@@ -38,8 +38,41 @@ struct UpsampleArgs {
     float mul;
 };
 
+// Register FIFO with a UNIFORM runtime index: one 16- or 32-wide vector per channel, which the
+// backend keeps in VGPRs and addresses relative to M0 (v_movrels/v_movreld) -- no scratch memory, no
+// select chains, and the marching loop can stay rolled.
+typedef float ofarn_f16v __attribute__((ext_vector_type(16)));
+typedef float ofarn_f32v __attribute__((ext_vector_type(32)));
+template <int B> struct FifoVec { typedef ofarn_f32v type; };
+template <> struct FifoVec<3> { typedef ofarn_f16v type; };
+template <> struct FifoVec<5> { typedef ofarn_f16v type; };
+template <> struct FifoVec<7> { typedef ofarn_f16v type; };
+template <> struct FifoVec<9> { typedef ofarn_f16v type; };
+template <> struct FifoVec<11> { typedef ofarn_f16v type; };
+template <> struct FifoVec<13> { typedef ofarn_f16v type; };
+template <> struct FifoVec<15> { typedef ofarn_f16v type; };
+
+// Timing-only ablations for profiling (never defined in the product build; results are wrong):
+//   OFARN_ABLATE 1: R1 taps not gathered (R0 reused)   2: no horizontal LDS pass   3: no f64 column sums
+//   OFARN_FI_WAVES: minimum waves per SIMD asked of the register allocator (default: none)
+#ifndef OFARN_ABLATE
+#define OFARN_ABLATE 0
+#endif
+#ifndef OFARN_FI_WAVES
+#define OFARN_FI_WAVES 3
+#endif
+#ifndef OFARN_FI_REGCH
+#define OFARN_FI_REGCH 3
+#endif
+#if OFARN_FI_WAVES > 0
+#define FI_BOUNDS __launch_bounds__(FI_THREADS, OFARN_FI_WAVES)
+#else
+#define FI_BOUNDS __launch_bounds__(FI_THREADS)
+#endif
+constexpr int FI_REGCH = OFARN_FI_REGCH;   // channels whose row FIFO lives in registers
+
 template <int M_, int MODE>   // MODE 0: flow_in == 0;  1: flow_in = upsample(coarse)*mul;  2: flow_in from HBM
-__global__ __launch_bounds__(FI_THREADS) void k_flow_iter(const float *__restrict__ R, int fstep,
+__global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
                                                           const float2 *__restrict__ flow_in,
                                                           float2 *__restrict__ flow_out, int w, int h,
                                                           int strip_h, double scale, UpsampleArgs up)
@@ -72,77 +105,166 @@ __global__ __launch_bounds__(FI_THREADS) void k_flow_iter(const float *__restric
         coarse = up.coarse + p * (size_t)up.cw * up.ch;
     }
 
-    auto matrices_at = [&](int yy, float m[5]) {
-        float dx = 0.f, dy = 0.f;
-        if (MODE == 2) {
-            const float2 d = fin[(size_t)yy * w + xc];
-            dx = d.x; dy = d.y;
-        } else if (MODE == 1) {
+    // ---- software pipeline -------------------------------------------------------------------
+    // Row r of the matrices needs the flow at (xc, r), then a flow-dependent gather.  Both are long
+    // latency, so they are issued one iteration (gather) and two iterations (flow) ahead of use and
+    // land while the f64 box sums of the current row run.
+    struct FlowRaw { float2 p00, p01, p10, p11; float b1; };
+    auto flow_issue = [&](int yy, FlowRaw &fr) {
+        if (MODE == 2) fr.p00 = ldg_f2(fin, ((unsigned)yy * (unsigned)w + (unsigned)xc) * 8u);
+        else if (MODE == 1) {
             const int sy = up.yofs[yy];
             const int sy1 = sy + 1 < up.ch ? sy + 1 : up.ch - 1;
-            const float b1 = up.ya[yy], b0 = 1.f - b1;
-            const float2 p00 = coarse[(size_t)sy * up.cw + usx], p01 = coarse[(size_t)sy * up.cw + usx1];
-            const float2 p10 = coarse[(size_t)sy1 * up.cw + usx], p11 = coarse[(size_t)sy1 * up.cw + usx1];
-            const float r0x = p00.x * ua0 + p01.x * ua1, r0y = p00.y * ua0 + p01.y * ua1;
-            const float r1x = p10.x * ua0 + p11.x * ua1, r1y = p10.y * ua0 + p11.y * ua1;
+            fr.b1 = up.ya[yy];
+            fr.p00 = coarse[(size_t)sy * up.cw + usx]; fr.p01 = coarse[(size_t)sy * up.cw + usx1];
+            fr.p10 = coarse[(size_t)sy1 * up.cw + usx]; fr.p11 = coarse[(size_t)sy1 * up.cw + usx1];
+        }
+    };
+    auto flow_finish = [&](const FlowRaw &fr, float &dx, float &dy) {
+        dx = 0.f; dy = 0.f;
+        if (MODE == 2) { dx = fr.p00.x; dy = fr.p00.y; }
+        else if (MODE == 1) {
+            const float b1 = fr.b1, b0 = 1.f - b1;
+            const float r0x = fr.p00.x * ua0 + fr.p01.x * ua1, r0y = fr.p00.y * ua0 + fr.p01.y * ua1;
+            const float r1x = fr.p10.x * ua0 + fr.p11.x * ua1, r1y = fr.p10.y * ua0 + fr.p11.y * ua1;
             dx = (r0x * b0 + r1x * b1) * up.mul;
             dy = (r0y * b0 + r1y * b1) * up.mul;
         }
-        update_matrices_px(R0, R1, npx, w, h, xc, yy, dx, dy, m);
     };
+    auto row_of = [&](int r) { return clampi(r, 0, h - 1); };
 
-    // register window: win[c][j] = M_c at row (y - M_ + j) of this thread's column
-    float win[5][TAPS];
+    // Column sums: block-restarted running sums in double (oracle OFO_BOX_BLOCKED).  Padded row t
+    // is matrix row clamp(t - M_); blocks of B = TAPS padded rows are aligned at t = 0, and y0 is a
+    // multiple of B.  fifo[c][j] holds M_c of the row at offset j of the previous block (the value
+    // that leaves the window), P the prefix of the current block, S what is left of the previous one.
+    // The loop stays rolled (the unrolled form is ~50 KB of code and thrashes the instruction cache);
+    // the register FIFO is a vector per channel indexed by the uniform block offset.
+    constexpr int B = TAPS;
+    // Channels 0..FI_REGCH-1 keep their FIFO in registers, the rest in LDS: the register budget
+    // decides how many waves fit a SIMD (<= 168 VGPRs for three), the LDS budget how many blocks a CU.
+    typename FifoVec<B>::type fifo[FI_REGCH];
+    __shared__ float sF[5 - FI_REGCH][B][FI_THREADS];
+    double P[5], S[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) { P[c] = 0; S[c] = 0; }
+#pragma unroll
+    for (int c = 0; c < FI_REGCH; c++) fifo[c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 5 - FI_REGCH; c++)
+        for (int q = 0; q < B; q++) sF[c][q][tid] = 0.f;
+    // Software pipeline: the gather of matrix row r+1 (and the flow of row r+2 it will depend on)
+    // is issued before the box sums of row r, so it lands while they run.
+    GatherRaw rawA;
+    FlowRaw frA{};
     {
-        float m[5];
-        int last = -1;
-        for (int j = 1; j < TAPS; j++) {      // rows y0-M_ .. y0+M_-1 go to slots 1..TAPS-1
-            const int yy = clampi(y0 - M_ + (j - 1), 0, h - 1);
-            if (yy != last) { matrices_at(yy, m); last = yy; }
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                // static indexing only: place via unrolled select
-#pragma unroll
-                for (int q = 1; q < TAPS; q++) if (q == j) win[c][q] = m[c];
-            }
-        }
+        float dx, dy;
+        flow_issue(row_of(y0 - M_), frA);
+        flow_finish(frA, dx, dy);
+        __builtin_amdgcn_sched_barrier(0);
+        flow_issue(row_of(y0 - M_ + 1), frA);
+        __builtin_amdgcn_sched_barrier(0);
+        gather_issue(R0, R1, npx, w, h, xc, row_of(y0 - M_), dx, dy, rawA);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    // here: rawA holds the matrix row of padded row t = y0, frA the flow of the row after it
 
+    const int nsteps = (y1 - y0) + B - 1;   // padded rows y0 .. y1+B-2; output y = t-(B-1)
     int buf = 0;
-    for (int y = y0; y < y1; y++) {
-        float m[5];
-        matrices_at(clampi(y + M_, 0, h - 1), m);
+    int j = 0;                               // offset of padded row t in its block (uniform)
+
+    auto do_row = [&](const int step, GatherRaw &raw, FlowRaw &fr) {
+        const int t = y0 + step;
+        float m[5], old[5];
+        matrices_finish(raw, w, h, xc, row_of(t - M_), m);
+        {
+            // vmcnt counts loads in issue order: the flow load goes FIRST in every step so that the
+            // wait for it (two steps later) does not also wait for the younger gathers behind it.
+            float dx, dy;
+            flow_finish(fr, dx, dy);
+            __builtin_amdgcn_sched_barrier(0);
+            flow_issue(row_of(t + 2 - M_), fr);
+            __builtin_amdgcn_sched_barrier(0);
+            gather_issue(R0, R1, npx, w, h, xc, row_of(t + 1 - M_), dx, dy, raw);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#if OFARN_ABLATE == 8      /* memory pattern only: loads + trivial ALU + store of the INPUT flow */
+        {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 5; c++) acc += m[c];
+            j = j + 1 == B ? 0 : j + 1;
+            if (step >= B - 1 && tid >= M_ && tid < FI_THREADS - M_ && x < w) {
+                float2 o = MODE == 2 ? ldg_f2(fin, ((unsigned)(t - (B - 1)) * (unsigned)w + (unsigned)x) * 8u) : make_float2(0.f, 0.f);
+                o.x += acc * 1e-30f;
+                stg_f2(fout, ((unsigned)(t - (B - 1)) * (unsigned)w + (unsigned)x) * 8u, o);
+            }
+            return;
+        }
+#endif
+        {
+            const int ju = __builtin_amdgcn_readfirstlane(j);
+#pragma unroll
+            for (int c = 0; c < FI_REGCH; c++) { old[c] = fifo[c][ju]; fifo[c][ju] = m[c]; }
+#pragma unroll
+            for (int c = FI_REGCH; c < 5; c++) { old[c] = sF[c - FI_REGCH][ju][tid]; sF[c - FI_REGCH][ju][tid] = m[c]; }
+        }
+        const bool emit = step >= B - 1;           // uniform: output row y = t-(B-1) >= y0
 #pragma unroll
         for (int c = 0; c < 5; c++) {
-#pragma unroll
-            for (int j = 0; j < TAPS - 1; j++) win[c][j] = win[c][j + 1];
-            win[c][TAPS - 1] = m[c];
-            double s = (double)win[c][0];
-#pragma unroll
-            for (int j = 1; j < TAPS; j++) s += (double)win[c][j];
-            sV[buf][c][tid] = s;
+            const double vn = (double)m[c];
+#if OFARN_ABLATE == 3
+            const double V = vn;
+#else
+            double V;
+            if (j == 0) P[c] = vn; else P[c] = P[c] + vn;
+            if (j == B - 1) { V = P[c]; S[c] = P[c]; }
+            else { S[c] = S[c] - (double)old[c]; V = S[c] + P[c]; }
+#endif
+            if (emit) sV[buf][c][tid] = V;
         }
-        __syncthreads();
+        j = j + 1 == B ? 0 : j + 1;
+        if (!emit) return;
+        const int y = t - (B - 1);
+        barrier_lds_only();
         if (tid >= M_ && tid < FI_THREADS - M_ && x < w) {
             double g[5];
 #pragma unroll
             for (int c = 0; c < 5; c++) {
                 const double *v = &sV[buf][c][tid - M_];
-                double s = v[0];
+#if OFARN_ABLATE == 2      /* one LDS read per channel instead of 15 */
+                g[c] = v[M_] * 15.0 * scale;
+#elif OFARN_ABLATE == 7    /* 15 LDS reads but no dependent add chain */
+                double s2 = 0;
 #pragma unroll
-                for (int i = 1; i < TAPS; i++) s += v[i];
-                g[c] = s * scale;
+                for (int i = 0; i < TAPS; i += 2) s2 += v[i];
+                g[c] = s2 * scale;
+#else
+                // LDS reads in two batches (register budget), each ahead of its adds
+                constexpr int H0 = (TAPS + 1) / 2;
+                double ta[H0], tb[TAPS - H0];
+#pragma unroll
+                for (int i = 0; i < H0; i++) ta[i] = v[i];
+                double s2 = ta[0];
+#pragma unroll
+                for (int i = 0; i < TAPS - H0; i++) tb[i] = v[H0 + i];
+#pragma unroll
+                for (int i = 1; i < H0; i++) s2 += ta[i];
+#pragma unroll
+                for (int i = 0; i < TAPS - H0; i++) s2 += tb[i];
+                g[c] = s2 * scale;
+#endif
             }
             const double idet = 1. / (g[0] * g[2] - g[1] * g[1] + 1e-3);
             float2 o;
             o.x = (float)((g[0] * g[4] - g[1] * g[3]) * idet);
             o.y = (float)((g[2] * g[3] - g[1] * g[4]) * idet);
-            fout[(size_t)y * w + x] = o;
+            stg_f2(fout, ((unsigned)y * (unsigned)w + (unsigned)x) * 8u, o);
         }
         buf ^= 1;
-    }
-}
+    };
 
+    for (int step = 0; step < nsteps; step++) do_row(step, rawA, frA);
+}
 
 // ---------------------------------------------------------------------------------------------
 // k_polyexp_march: FarnebackPolyExp (stage B) with compile-time radius N, marching layout.
@@ -299,9 +421,13 @@ void launch_flow_iter(hipStream_t s, const float *R, int fstep, const float *flo
 {
     constexpr int M_ = 7;
     constexpr int OUTW = FI_THREADS - 2 * M_;
+    constexpr int B = 2 * M_ + 1;
+    // strips start on block boundaries of the blocked column sums (multiples of B rows)
+    const int nblk = (h + B - 1) / B;
     int nstrips = (h + 64) / 128;
     if (nstrips < 1) nstrips = 1;
-    const int strip_h = (h + nstrips - 1) / nstrips;
+    if (nstrips > nblk) nstrips = nblk;
+    const int strip_h = ((nblk + nstrips - 1) / nstrips) * B;
     dim3 grid(cdivu(w, OUTW), cdivu(h, strip_h), npairs);
     const double scale = 1. / ((double)winsize * winsize);
     UpsampleArgs up{reinterpret_cast<const float2 *>(coarse), cw, ch, d_xofs, d_xa, d_yofs, d_ya, mul};

@@ -4,7 +4,7 @@
 // path; kernels_fast.hip holds the specialisations the default parameter set dispatches to.
 //
 // Arithmetic contract: every kernel performs, per output element, the same IEEE-754 operations in
-// the same order as oracle/farneback_oracle.c (box order OFO_BOX_DIRECT), so results can be
+// the same order as oracle/farneback_oracle.c (box order OFO_BOX_BLOCKED), so results can be
 // compared bit for bit.  The library is built with -ffp-contract=off: no FMA contraction.
 //
 // Which OpenCV function each kernel stands for is given per kernel.
@@ -207,56 +207,66 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
 
 // ---------------------------------------------------------------------------------------------
 // Stage D.  FarnebackUpdateFlow_Blur: (2m+1)x(2m+1) box sum with replicate borders, scaled by
-// 1/winsize^2, then the regularised 2x2 solve.  Sums in double, in the fixed order
-//   column: sum_{j=-m..m} (double)M[clamp(y+j)][x],  window: sum_{i=-m..m} colsum[clamp(x+i)]
-// (oracle OFO_BOX_DIRECT).  One 64x16 tile per block, one channel at a time through LDS.
+// 1/winsize^2, then the regularised 2x2 solve.  All sums in double.
+//   columns: block-restarted running sums (oracle OFO_BOX_BLOCKED): with B = 2m+1, padded rows
+//            r' (row r'-m clamped) and aligned blocks of B rows,
+//              T_b = v[Bb] + ... + v[Bb+B-1] (left to right), S_b(j) = S_b(j-1) - v[Bb+j-1],
+//              colsum(Bb) = T_b,  colsum(Bb+j) = S_b(j) + P_{b+1}(j-1)
+//   rows:    sum_{i=-m..m} colsum[clamp(x+i)] left to right.
+// One block = TW columns x one aligned block-row of B output rows; one channel at a time:
+// phase A, one thread per column (with halo) marches the B outputs reading M straight from
+// HBM/L2 (coalesced across columns); phase B sums horizontally out of LDS.
 // ---------------------------------------------------------------------------------------------
-constexpr int BS_TW = 64, BS_TH = 16;
+constexpr int BS_MAXOUT = 8;   // outputs per thread: TW * B <= 256 * BS_MAXOUT
 
 __global__ __launch_bounds__(256) void k_blur_solve(const float *__restrict__ M, float2 *__restrict__ flow,
-                                                     int w, int h, int m, double scale)
+                                                     int w, int h, int m, int TW, double scale)
 {
-    extern __shared__ double smem_d[];
-    const int IW = BS_TW + 2 * m, IH = BS_TH + 2 * m;
-    double *sV = smem_d;                                   // [BS_TH][IW] column sums
-    float *sM = reinterpret_cast<float *>(sV + BS_TH * IW);  // [IH][IW]
-    const int x0 = blockIdx.x * BS_TW, y0 = blockIdx.y * BS_TH;
+    extern __shared__ double sV[];   // [B][IW]
+    const int B = 2 * m + 1, IW = TW + 2 * m;
+    const int x0 = blockIdx.x * TW, yb = blockIdx.y * B;   // yb: first output row = first padded row
     const size_t npx = (size_t)w * h;
     const int tid = threadIdx.x;
-    const int ox = tid & 63, oy = tid >> 6;   // thread handles rows oy, oy+4, oy+8, oy+12
-    double acc[4][5];
+    const int nout = TW * B;
+    double acc[BS_MAXOUT][5];
 
     for (int c = 0; c < 5; c++) {
         const float *src = M + ((size_t)blockIdx.z * 5 + c) * npx;
-        for (int i = tid; i < IH * IW; i += 256) {
-            const int ly = i / IW, lx = i - ly * IW;
-            const int gx = clampi(x0 - m + lx, 0, w - 1), gy = clampi(y0 - m + ly, 0, h - 1);
-            sM[i] = src[(size_t)gy * w + gx];
-        }
-        __syncthreads();
-        for (int i = tid; i < BS_TH * IW; i += 256) {
-            const int ly = i / IW, lx = i - ly * IW;
-            const float *col = sM + ly * IW + lx;
-            double s = (double)col[0];
-            for (int j = 1; j <= 2 * m; j++) s += (double)col[j * IW];
-            sV[i] = s;
+        for (int i = tid; i < IW; i += 256) {
+            const float *col = src + clampi(x0 - m + i, 0, w - 1);
+            auto v = [&](int t) { return (double)col[(size_t)clampi(t - m, 0, h - 1) * w]; };
+            double P = v(yb);
+            for (int j = 1; j < B; j++) P = P + v(yb + j);
+            sV[i] = P;
+            double S = P, Pn = 0;
+            for (int j = 1; j < B && yb + j < h; j++) {
+                S = S - v(yb + j - 1);
+                const double vn = v(yb + B + j - 1);
+                Pn = j == 1 ? vn : Pn + vn;
+                sV[j * IW + i] = S + Pn;
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const double *rowv = sV + (oy + 4 * q) * IW + ox;
-            double s = rowv[0];
-            for (int i = 1; i <= 2 * m; i++) s += rowv[i];
-            acc[q][c] = s;
+        for (int q = 0; q < BS_MAXOUT; q++) {
+            const int idx = tid + 256 * q;
+            if (idx < nout) {
+                const int ly = idx / TW, ox = idx - ly * TW;
+                const double *rowv = sV + ly * IW + ox;
+                double s = rowv[0];
+                for (int i = 1; i <= 2 * m; i++) s += rowv[i];
+                acc[q][c] = s;
+            }
         }
         __syncthreads();
     }
-    const int gx = x0 + ox;
-    if (gx >= w) return;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int gy = y0 + oy + 4 * q;
-        if (gy >= h) continue;
+    for (int q = 0; q < BS_MAXOUT; q++) {
+        const int idx = tid + 256 * q;
+        if (idx >= nout) continue;
+        const int ly = idx / TW, ox = idx - ly * TW;
+        const int gx = x0 + ox, gy = yb + ly;
+        if (gx >= w || gy >= h) continue;
         const double g11 = acc[q][0] * scale, g12 = acc[q][1] * scale, g22 = acc[q][2] * scale;
         const double h1 = acc[q][3] * scale, h2 = acc[q][4] * scale;
         const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
@@ -403,14 +413,23 @@ void launch_update_matrices(hipStream_t s, const float *R, int fstep, const floa
                        reinterpret_cast<const float2 *>(flow), M, w, h);
 }
 
+int blur_solve_max_winsize() { return 127; }
+
 void launch_blur_solve(hipStream_t s, const float *M, float *flow, int w, int h, int npairs, int winsize)
 {
-    const int m = winsize / 2;
-    const int IW = BS_TW + 2 * m, IH = BS_TH + 2 * m;
-    const size_t lds = sizeof(double) * (size_t)(BS_TH * IW) + sizeof(float) * (size_t)(IH * IW);
+    const int m = winsize / 2, B = 2 * m + 1;
+    int TW = 64;
+    while (TW > 8 && (TW * B > 256 * BS_MAXOUT || (size_t)B * (TW + 2 * m) * 8 > 150 * 1024)) TW >>= 1;
+    const size_t lds = sizeof(double) * (size_t)B * (TW + 2 * m);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_blur_solve),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
     const double scale = 1. / ((double)winsize * winsize);
-    dim3 grid(cdiv(w, BS_TW), cdiv(h, BS_TH), npairs);
-    hipLaunchKernelGGL(k_blur_solve, grid, dim3(256), lds, s, M, reinterpret_cast<float2 *>(flow), w, h, m,
+    dim3 grid(cdiv(w, TW), cdiv(h, B), npairs);
+    hipLaunchKernelGGL(k_blur_solve, grid, dim3(256), lds, s, M, reinterpret_cast<float2 *>(flow), w, h, m, TW,
                        scale);
 }
 

@@ -194,7 +194,8 @@ int check_params(const ofarn_params *p)
     if (!(p->pyr_scale < 1) || !(p->pyr_scale > 0))
         return fail(OFARN_E_INVALID, "pyr_scale must be in (0, 1) (cv2: CV_Assert(pyrScale_ < 1)), got %g", p->pyr_scale);
     if (p->levels < 0) return fail(OFARN_E_INVALID, "levels must be >= 0, got %d", p->levels);
-    if (p->winsize < 2) return fail(OFARN_E_INVALID, "winsize must be >= 2, got %d", p->winsize);
+    if (p->winsize < 2 || p->winsize > blur_solve_max_winsize())
+        return fail(OFARN_E_INVALID, "winsize must be in [2, %d], got %d", blur_solve_max_winsize(), p->winsize);
     if (p->iterations < 0) return fail(OFARN_E_INVALID, "iterations must be >= 0, got %d", p->iterations);
     if (p->poly_n < 1 || p->poly_n > kMaxPolyN)
         return fail(OFARN_E_INVALID, "poly_n must be in [1, %d], got %d", kMaxPolyN, p->poly_n);

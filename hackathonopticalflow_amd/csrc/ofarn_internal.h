@@ -48,6 +48,7 @@ void launch_update_matrices(hipStream_t s, const float *R, int fstep, const floa
 // Stage D: box average + 2x2 solve
 void launch_blur_solve(hipStream_t s, const float *M, float *flow, int w, int h, int npairs,
                        int winsize);
+int blur_solve_max_winsize();
 // Stages (E+)C+D fused (kernels_fast.hip).  mode 0: zero input flow; 1: input flow is
 // upsample(coarse)*mul computed on the fly; 2: input flow read from flow_in.  flow_out != flow_in.
 bool flow_iter_supported(int winsize);

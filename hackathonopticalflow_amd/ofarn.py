@@ -22,7 +22,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libofarn.so")
+# OFARN_LIB selects an experimental build of the same C-ABI (profiling ablations); default = product
+LIB_PATH = os.environ.get("OFARN_LIB") or os.path.join(_HERE, "libofarn.so")
 
 OFARN_OK = 0
 OFARN_E_INVALID = -1

@@ -27,8 +27,8 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
  * this library.  The product (hackathonopticalflow_amd) never does.
  *
- * Two summation orders are offered for the winsize x winsize box average
- * (OFO_BOX_RUNNING / OFO_BOX_DIRECT); see ofo_update_flow_blur().
+ * Three summation orders are offered for the winsize x winsize box average
+ * (OFO_BOX_RUNNING / OFO_BOX_DIRECT / OFO_BOX_BLOCKED); see ofo_update_flow_blur().
  */
 #include <math.h>
 #include <stdint.h>
@@ -49,7 +49,8 @@
 static const float ofo_border_tab[OFO_BORDER] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
 
 #define OFO_BOX_RUNNING 0   /* OpenCV's literal order: double running sums, float row differences */
-#define OFO_BOX_DIRECT  1   /* same window, each sum taken directly in a fixed order (device order) */
+#define OFO_BOX_DIRECT  1   /* same window, each sum taken directly in a fixed order                */
+#define OFO_BOX_BLOCKED 2   /* column sums as block-restarted running sums (the HIP kernels' order)  */
 
 typedef struct ofo_params {
     double pyr_scale;
@@ -434,8 +435,19 @@ static inline void ofo_solve(double g11, double g12, double g22, double h1, doub
  *   window is a double running sum along the row.
  * box_mode OFO_BOX_DIRECT: the same (2m+1)x(2m+1) replicate-border window, but every sum is
  *   taken directly: column sum = sum_{j=-m..m} (double)M[clamp(y+j)][x] in that order, then
- *   window sum = sum_{i=-m..m} colsum[clamp(x+i)] in that order.  This is the order the HIP
- *   kernel uses, so the device result can be compared bit for bit.
+ *   window sum = sum_{i=-m..m} colsum[clamp(x+i)] in that order.
+ * box_mode OFO_BOX_BLOCKED: like OpenCV the column sums are RUNNING sums in double (add the row
+ *   entering the window, subtract the row leaving it), but restarted every B = 2m+1 rows so that a
+ *   GPU strip can start anywhere without the history of the rows above it, and without OpenCV's
+ *   float rounding of the row difference.  With padded rows r' = 0..h+2m-1, v[r'] =
+ *   (double)M[clamp(r'-m)][x], and aligned blocks b = [B*b, B*b+B-1]:
+ *       P_b(j) = v[Bb] + v[Bb+1] + ... + v[Bb+j]          accumulated left to right
+ *       T_b    = P_b(B-1)
+ *       S_b(0) = T_b;  S_b(j) = S_b(j-1) - v[Bb+j-1]       (what is left of block b from offset j)
+ *       colsum(y) = T_b                    if y = B*b
+ *                 = S_b(j) + P_{b+1}(j-1)  if y = B*b + j, 0 < j < B
+ *   The horizontal pass is the direct left-to-right sum of OFO_BOX_DIRECT.  This is the order the
+ *   HIP kernels use, so device results can be compared bit for bit.
  * OpenCV re-runs UpdateMatrices on row stripes as soon as the blur has passed them; a stripe is
  * only rewritten after its last reader, so that schedule equals the two-phase form used here. */
 OFO_API void ofo_update_flow_blur(const float *R0, const float *R1, float *flow_, float *M,
@@ -480,16 +492,42 @@ OFO_API void ofo_update_flow_blur(const float *R0, const float *R1, float *flow_
             }
         }
     } else {
+        /* per column-channel state of the blocked running sums */
+        const int B = 2 * m + 1;
+        double *P = NULL, *S = NULL;
+        if (box_mode == OFO_BOX_BLOCKED) {
+            P = (double *)calloc((size_t)width * 5, sizeof(double));
+            S = (double *)calloc((size_t)width * 5, sizeof(double));
+        }
         for (int y = 0; y < height; y++) {
             float *flow = flow_ + (size_t)y * width * 2;
-            {
+            if (box_mode == OFO_BOX_DIRECT) {
                 const float *srow = M + (size_t)(y - m < 0 ? 0 : y - m) * width * 5;
                 for (int x = 0; x < width * 5; x++) vsum[x] = (double)srow[x];
-            }
-            for (int j = -m + 1; j <= m; j++) {
-                int yy = y + j; if (yy < 0) yy = 0; if (yy > height - 1) yy = height - 1;
-                const float *srow = M + (size_t)yy * width * 5;
-                for (int x = 0; x < width * 5; x++) vsum[x] += (double)srow[x];
+                for (int j = -m + 1; j <= m; j++) {
+                    int yy = y + j; if (yy < 0) yy = 0; if (yy > height - 1) yy = height - 1;
+                    srow = M + (size_t)yy * width * 5;
+                    for (int x = 0; x < width * 5; x++) vsum[x] += (double)srow[x];
+                }
+            } else {
+                /* padded rows arrive one per output row; output y is emitted when padded row
+                 * t = y + B - 1 has arrived.  Rows 0..B-2 are consumed before the first output. */
+                for (int t = (y == 0 ? 0 : y + B - 1); t <= y + B - 1; t++) {
+                    const int j = t % B;                       /* offset of row t in its block */
+                    int rnew = t - m; if (rnew < 0) rnew = 0; if (rnew > height - 1) rnew = height - 1;
+                    int rold = t - B - m; if (rold < 0) rold = 0; if (rold > height - 1) rold = height - 1;
+                    const float *snew = M + (size_t)rnew * width * 5;
+                    const float *sold = M + (size_t)rold * width * 5;   /* row t-B: same offset, previous block */
+                    for (int x = 0; x < width * 5; x++) {
+                        const double vn = (double)snew[x];
+                        P[x] = j == 0 ? vn : P[x] + vn;
+                        if (j == B - 1) { vsum[x] = P[x]; S[x] = P[x]; }
+                        else {
+                            if (t >= B) S[x] = S[x] - (double)sold[x];
+                            vsum[x] = S[x] + P[x];
+                        }
+                    }
+                }
             }
             for (int x = 0; x < width; x++) {
                 double s[5];
@@ -502,6 +540,7 @@ OFO_API void ofo_update_flow_blur(const float *R0, const float *R1, float *flow_
                 ofo_solve(s[0], s[1], s[2], s[3], s[4], scale, flow + x * 2);
             }
         }
+        free(P); free(S);
     }
     free(_vsum);
     if (update_matrices) ofo_update_matrices(R0, R1, flow_, M, width, height, 0, height);

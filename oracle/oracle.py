@@ -25,7 +25,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _BUILD = os.path.join(_HERE, "_build")
 
 BOX_RUNNING = 0  # OpenCV's literal running-sum order
-BOX_DIRECT = 1   # direct fixed-order window sums (the order the HIP kernels use)
+BOX_DIRECT = 1   # direct fixed-order window sums
+BOX_BLOCKED = 2  # block-restarted running column sums in double (the order the HIP kernels use)
 
 
 class OfoParams(C.Structure):

@@ -5,7 +5,7 @@
 The reference ships no fixtures for its Farneback path and cv2 cannot be imported here (SURVEY.md
 8c), so these vectors are outputs of the repo's own oracle, PARITY UNPINNED against real OpenCV.
 They pin (a) the oracle against accidental change and (b) the HIP path on the GPU box, where they
-are compared bit for bit (flow_direct) and within tolerance (flow_running = OpenCV's literal order).
+are compared bit for bit (flow_direct: the device summation order) and within tolerance (flow_running = OpenCV's literal order).
 """
 import os
 import sys
@@ -29,7 +29,7 @@ def main():
     out = os.path.dirname(os.path.abspath(__file__))
     for name, (h, w, seed, kw) in CASES.items():
         prev, nxt, shift = translated_pair(h, w, seed, max_shift=4)
-        fd = O.farneback(prev, nxt, box_mode=O.BOX_DIRECT, **kw)
+        fd = O.farneback(prev, nxt, box_mode=O.BOX_BLOCKED, **kw)
         fr = O.farneback(prev, nxt, box_mode=O.BOX_RUNNING, **kw)
         mask, v = O.danger_map_numpy(fd, w, h, 30)
         np.savez_compressed(os.path.join(out, name + ".npz"), prev=prev, next=nxt, shift=np.int64(shift),

@@ -2,8 +2,8 @@
 
 Bar (north_star): flow within a stated EPE tolerance of the OpenCV-algorithm oracle; danger-point
 index sets bit-identical.  What is asserted here:
-  * every stage, and the whole pipeline, BIT-EXACT against the oracle run with the direct box-sum
-    order (oracle BOX_DIRECT: same IEEE operations in the same order as the kernels);
+  * every stage, and the whole pipeline, BIT-EXACT against the oracle run with the block-restarted
+    running-sum box order (oracle BOX_BLOCKED: same IEEE operations in the same order as the kernels);
   * against the oracle in OpenCV's literal running-sum order: mean EPE <= 1e-5 px and
     max EPE <= 1e-3 px (TOL_* below) -- the only difference is the summation order of the box filter;
   * danger mask bit-exact against the reference's NumPy filter on the same flow.
@@ -74,12 +74,13 @@ def test_stage_update_matrices_bit_exact(H, oracle, w, h):
     np.testing.assert_array_equal(got, planar(oracle.update_matrices(R0, R1, flow)))
 
 
-@pytest.mark.parametrize("w,h,winsize", [(320, 240, 15), (97, 83, 9), (70, 50, 8), (40, 33, 3), (64, 48, 41)])
+@pytest.mark.parametrize("w,h,winsize", [(320, 240, 15), (97, 83, 9), (70, 50, 8), (40, 33, 3), (64, 48, 41),
+                                         (300, 200, 127), (33, 100, 2)])
 def test_stage_blur_solve_bit_exact(H, oracle, w, h, winsize):
     rng = np.random.default_rng(3)
     M = (rng.standard_normal((h, w, 5)) * 10).astype(np.float32)
     z5, z2 = np.zeros((h, w, 5), np.float32), np.zeros((h, w, 2), np.float32)
-    ref, _ = oracle.update_flow_blur(z5, z5, z2, M, winsize, False, oracle.BOX_DIRECT)
+    ref, _ = oracle.update_flow_blur(z5, z5, z2, M, winsize, False, oracle.BOX_BLOCKED)
     with H.FarnebackEngine(w, h, 1, winsize=winsize) as eng:
         got = eng.stage_blur_solve(planar(M))
     np.testing.assert_array_equal(got, ref)
@@ -111,7 +112,7 @@ def test_pipeline_vs_oracle(H, oracle, w, h, seed, kw):
     prev, nxt, _ = translated_pair(h, w, seed, max_shift=5)
     got = H.calculate_optical_flow(prev, nxt, **kw)
     assert got.shape == (h, w, 2) and got.dtype == np.float32
-    np.testing.assert_array_equal(got, oracle.farneback(prev, nxt, box_mode=oracle.BOX_DIRECT, **kw))
+    np.testing.assert_array_equal(got, oracle.farneback(prev, nxt, box_mode=oracle.BOX_BLOCKED, **kw))
     e = epe(got, oracle.farneback(prev, nxt, box_mode=oracle.BOX_RUNNING, **kw))
     assert e.mean() <= TOL_MEAN_EPE and e.max() <= TOL_MAX_EPE, (e.mean(), e.max())
 
@@ -134,7 +135,7 @@ def test_generic_and_fused_paths_agree(H, oracle, monkeypatch):
     """winsize 15 dispatches to the fused marching kernel; OFARN_FORCE_GENERIC=1 keeps the unfused
     generic kernels.  Both must equal the oracle bit for bit (multi-strip, multi-block sizes)."""
     prev, nxt, _ = translated_pair(300, 520, 41, max_shift=6)
-    ref = oracle.farneback(prev, nxt, levels=2, box_mode=oracle.BOX_DIRECT)
+    ref = oracle.farneback(prev, nxt, levels=2, box_mode=oracle.BOX_BLOCKED)
     with H.FarnebackEngine(520, 300, 1, levels=2) as eng:
         np.testing.assert_array_equal(eng.calc(prev, nxt), ref)
     monkeypatch.setenv("OFARN_FORCE_GENERIC", "1")
@@ -142,7 +143,7 @@ def test_generic_and_fused_paths_agree(H, oracle, monkeypatch):
         np.testing.assert_array_equal(eng.calc(prev, nxt), ref)
     monkeypatch.delenv("OFARN_FORCE_GENERIC")
     for iters in (1, 2, 4):
-        ref = oracle.farneback(prev, nxt, levels=1, iterations=iters, box_mode=oracle.BOX_DIRECT)
+        ref = oracle.farneback(prev, nxt, levels=1, iterations=iters, box_mode=oracle.BOX_BLOCKED)
         np.testing.assert_array_equal(H.calculate_optical_flow(prev, nxt, levels=1, iterations=iters), ref)
 
 
@@ -150,7 +151,7 @@ def test_pipeline_1080p_L5_config2(H, oracle):
     """BASELINE config 2: one 1920x1080 pair, levels=5, iterations=3, seed 2001."""
     prev, nxt, (tx, ty) = translated_pair(1080, 1920, 2001)
     got = H.calculate_optical_flow(prev, nxt, levels=5)
-    ref = oracle.farneback(prev, nxt, levels=5, box_mode=oracle.BOX_DIRECT)
+    ref = oracle.farneback(prev, nxt, levels=5, box_mode=oracle.BOX_BLOCKED)
     np.testing.assert_array_equal(got, ref)
     e = epe(got, oracle.farneback(prev, nxt, levels=5))
     assert e.mean() <= TOL_MEAN_EPE and e.max() <= TOL_MAX_EPE, (e.mean(), e.max())
@@ -185,7 +186,7 @@ def test_strided_input(H, oracle):
     big_p, big_n, _ = translated_pair(200, 300, 31)
     prev, nxt = big_p[10:170, 20:260], big_n[10:170, 20:260]    # non-contiguous views
     got = H.calculate_optical_flow(prev, nxt, levels=2)
-    ref = oracle.farneback(np.ascontiguousarray(prev), np.ascontiguousarray(nxt), levels=2, box_mode=oracle.BOX_DIRECT)
+    ref = oracle.farneback(np.ascontiguousarray(prev), np.ascontiguousarray(nxt), levels=2, box_mode=oracle.BOX_BLOCKED)
     np.testing.assert_array_equal(got, ref)
 
 
@@ -194,7 +195,7 @@ def test_batch_modes_and_waves(H, oracle):
     h, w, n_pairs = 120, 160, 5
     frames, _ = translated_pairs(n_pairs, h, w, 3000, max_shift=4)
     kw = dict(levels=2)
-    ref = np.stack([oracle.farneback(frames[2 * i], frames[2 * i + 1], box_mode=oracle.BOX_DIRECT, **kw)
+    ref = np.stack([oracle.farneback(frames[2 * i], frames[2 * i + 1], box_mode=oracle.BOX_BLOCKED, **kw)
                     for i in range(n_pairs)])
     for wave in (1, 2, 8):
         with H.FarnebackEngine(w, h, wave, **kw) as eng:
@@ -209,7 +210,7 @@ def test_batch_modes_and_waves(H, oracle):
             assert flow_c.shape[0] == 5
             np.testing.assert_array_equal(flow_c[0], ref[0])
             np.testing.assert_array_equal(flow_c[2], ref[1])
-            mid = oracle.farneback(frames[1], frames[2], box_mode=oracle.BOX_DIRECT, **kw)
+            mid = oracle.farneback(frames[1], frames[2], box_mode=oracle.BOX_BLOCKED, **kw)
             np.testing.assert_array_equal(flow_c[1], mid)
 
 
@@ -257,7 +258,7 @@ def test_device_resident_batch_torch(H, oracle):
         torch.cuda.synchronize()
         flow = d_flow.cpu().numpy()
         for i in range(n_pairs):
-            ref = oracle.farneback(frames[2 * i], frames[2 * i + 1], levels=2, box_mode=oracle.BOX_DIRECT)
+            ref = oracle.farneback(frames[2 * i], frames[2 * i + 1], levels=2, box_mode=oracle.BOX_BLOCKED)
             np.testing.assert_array_equal(flow[i], ref)
             m_ref, _ = oracle.danger_map_numpy(flow[i], w, h, 30)
             np.testing.assert_array_equal(d_mask[i].cpu().numpy(), m_ref)
