@@ -12,8 +12,25 @@ __device__ __forceinline__ int reflect101(int p, int len)
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// R layout ("4+1"): per frame, channels 0..3 of pixel o as one aligned float4 at ((float4*)R)[o],
+// channel 4 as a float at R[4*npx + o].  One 16-byte and one 4-byte load per pixel instead of five
+// 4-byte loads: the texture addresser works per lane and cycle, so wide per-lane loads are what
+// moves bytes (measured: the 26 dword loads of the planar layout took a third of flow_iter's time
+// just to issue).
+__device__ __forceinline__ void load_r(const float *__restrict__ Rf, size_t npx, unsigned o, float out[5])
+{
+    const float4 a = reinterpret_cast<const float4 *>(Rf)[o];
+    out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
+    out[4] = Rf[4 * npx + o];
+}
+__device__ __forceinline__ void store_r(float *__restrict__ Rf, size_t npx, unsigned o, const float v[5])
+{
+    reinterpret_cast<float4 *>(Rf)[o] = make_float4(v[0], v[1], v[2], v[3]);
+    Rf[4 * npx + o] = v[4];
+}
+
 // FarnebackUpdateMatrices for one pixel (optflowgf.cpp), all float32, no FMA contraction.
-// R0, R1: channel-planar [5][h][w] of the pair's two frames; (dx, dy) the current flow at (x, y).
+// R0, R1: the pair's two frames in the 4+1 layout; (dx, dy) the current flow at (x, y).
 __device__ __forceinline__ void update_matrices_px(const float *__restrict__ R0, const float *__restrict__ R1,
                                                     size_t npx, int w, int h, int x, int y, float dx,
                                                     float dy, float out[5])
@@ -21,28 +38,32 @@ __device__ __forceinline__ void update_matrices_px(const float *__restrict__ R0,
     float fx = (float)x + dx, fy = (float)y + dy;
     const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
     fx -= (float)x1; fy -= (float)y1;
-    const size_t o = (size_t)y * w + x;
+    const unsigned o = (unsigned)y * (unsigned)w + (unsigned)x;
+    float c0[5];
+    load_r(R0, npx, o, c0);
     float r2, r3, r4, r5, r6;
     if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
         const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        const size_t q = (size_t)y1 * w + x1;
-        const float *p = R1 + q;
-        r2 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += npx;
-        r3 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += npx;
-        r4 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += npx;
-        r5 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += npx;
-        r6 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1];
-        r4 = (R0[2 * npx + o] + r4) * 0.5f;
-        r5 = (R0[3 * npx + o] + r5) * 0.5f;
-        r6 = (R0[4 * npx + o] + r6) * 0.25f;
+        const unsigned q = (unsigned)y1 * (unsigned)w + (unsigned)x1;
+        float t00[5], t01[5], t10[5], t11[5];
+        load_r(R1, npx, q, t00); load_r(R1, npx, q + 1, t01);
+        load_r(R1, npx, q + w, t10); load_r(R1, npx, q + w + 1, t11);
+        r2 = a00 * t00[0] + a01 * t01[0] + a10 * t10[0] + a11 * t11[0];
+        r3 = a00 * t00[1] + a01 * t01[1] + a10 * t10[1] + a11 * t11[1];
+        r4 = a00 * t00[2] + a01 * t01[2] + a10 * t10[2] + a11 * t11[2];
+        r5 = a00 * t00[3] + a01 * t01[3] + a10 * t10[3] + a11 * t11[3];
+        r6 = a00 * t00[4] + a01 * t01[4] + a10 * t10[4] + a11 * t11[4];
+        r4 = (c0[2] + r4) * 0.5f;
+        r5 = (c0[3] + r5) * 0.5f;
+        r6 = (c0[4] + r6) * 0.25f;
     } else {
         r2 = r3 = 0.f;
-        r4 = R0[2 * npx + o];
-        r5 = R0[3 * npx + o];
-        r6 = R0[4 * npx + o] * 0.5f;
+        r4 = c0[2];
+        r5 = c0[3];
+        r6 = c0[4] * 0.5f;
     }
-    r2 = (R0[o] - r2) * 0.5f;
-    r3 = (R0[npx + o] - r3) * 0.5f;
+    r2 = (c0[0] - r2) * 0.5f;
+    r3 = (c0[1] - r3) * 0.5f;
     r2 = r2 + (r4 * dy + r6 * dx);
     r3 = r3 + (r6 * dy + r5 * dx);
     if ((unsigned)(x - kBorder) >= (unsigned)(w - kBorder * 2) ||
@@ -93,35 +114,19 @@ __device__ __forceinline__ void gather_issue(const float *__restrict__ R0, const
     const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
     fx -= (float)x1; fy -= (float)y1;
     g.dx = dx; g.dy = dy; g.fx = fx; g.fy = fy;
-    // 32-bit element offsets on uniform (scalar) plane bases: one VGPR per address instead of two
     const unsigned o = (unsigned)y * (unsigned)w + (unsigned)x;
-#pragma unroll
-#if defined(OFARN_ABLATE) && OFARN_ABLATE == 6   /* no R loads at all */
-    for (int c = 0; c < 5; c++) g.r0[c] = dx * (float)(c + 1) + fy;
-#else
-    for (int c = 0; c < 5; c++) g.r0[c] = ldg_f32(R0 + c * npx, o * 4u);
-#endif
+    load_r(R0, npx, o, g.r0);
     g.inb = ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) ? 1 : 0;
-    // out-of-range taps are never used; read a valid address instead so the loads stay unconditional
+    // out-of-range taps are never used; read pixel 0 instead so the loads stay unconditional
     const unsigned q = g.inb ? (unsigned)y1 * (unsigned)w + (unsigned)x1 : 0u;
     const unsigned q01 = g.inb ? q + 1u : 0u, q10 = g.inb ? q + (unsigned)w : 0u, q11 = g.inb ? q + (unsigned)w + 1u : 0u;
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        const float *p = R1 + c * npx;
 #if defined(OFARN_ABLATE) && (OFARN_ABLATE == 1 || OFARN_ABLATE == 6)
-        (void)p; (void)q01; (void)q10; (void)q11;
-        g.t00[c] = g.r0[c]; g.t01[c] = g.r0[c]; g.t10[c] = g.r0[c]; g.t11[c] = g.r0[c];
-#elif defined(OFARN_ABLATE) && OFARN_ABLATE == 4   /* taps at the pixel itself: same load count, no gather */
-        g.t00[c] = ldg_f32(p, o * 4u); g.t01[c] = ldg_f32(p, o * 4u + 4u);
-        g.t10[c] = ldg_f32(p, (o + (unsigned)w) * 4u); g.t11[c] = ldg_f32(p, (o + (unsigned)w) * 4u + 4u);
-#elif defined(OFARN_ABLATE) && OFARN_ABLATE == 5   /* half the tap loads */
-        g.t00[c] = ldg_f32(p, q * 4u); g.t01[c] = g.t00[c];
-        g.t10[c] = ldg_f32(p, q10 * 4u); g.t11[c] = g.t10[c];
+    (void)q01; (void)q10; (void)q11;
+    for (int c = 0; c < 5; c++) { g.t00[c] = g.r0[c]; g.t01[c] = g.r0[c]; g.t10[c] = g.r0[c]; g.t11[c] = g.r0[c]; }
 #else
-        g.t00[c] = ldg_f32(p, q * 4u); g.t01[c] = ldg_f32(p, q01 * 4u);
-        g.t10[c] = ldg_f32(p, q10 * 4u); g.t11[c] = ldg_f32(p, q11 * 4u);
+    load_r(R1, npx, q, g.t00); load_r(R1, npx, q01, g.t01);
+    load_r(R1, npx, q10, g.t10); load_r(R1, npx, q11, g.t11);
 #endif
-    }
 }
 
 // Branch-free: a divergent branch here makes the compiler drain every outstanding load at the

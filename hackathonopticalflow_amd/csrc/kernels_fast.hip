@@ -24,6 +24,8 @@
 #include "farneback_device.h"
 #include "ofarn_internal.h"
 
+#include <cstdio>
+
 namespace ofarn {
 
 constexpr int FI_THREADS = 256;
@@ -36,6 +38,7 @@ struct UpsampleArgs {
     const int *yofs;
     const float *ya;
     float mul;
+    unsigned long long *dbg;   // OFARN_STAMPS diagnostic build only: per-segment cycle sums
 };
 
 // Register FIFO with a UNIFORM runtime index: one 16- or 32-wide vector per channel, which the
@@ -69,7 +72,23 @@ template <> struct FifoVec<15> { typedef ofarn_f16v type; };
 #else
 #define FI_BOUNDS __launch_bounds__(FI_THREADS)
 #endif
-constexpr int FI_REGCH = OFARN_FI_REGCH;   // channels whose row FIFO lives in registers
+constexpr int FI_REGCH = OFARN_FI_REGCH;
+
+// OFARN_STAMPS: diagnostic build that sums s_memtime differences per loop segment (never in the
+// product build; its fences forbid overlaps the real kernel has -- read shares, not lengths).
+#ifdef OFARN_STAMPS
+#define STAMP(k)                                                                              \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t_;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        seg[k] += t_ - tprev;                                                                 \
+        tprev = t_;                                                                           \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif   // channels whose row FIFO lives in registers
 
 template <int M_, int MODE>   // MODE 0: flow_in == 0;  1: flow_in = upsample(coarse)*mul;  2: flow_in from HBM
 __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
@@ -88,8 +107,8 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
     const int y1 = min(y0 + strip_h, h);
     const size_t npx = (size_t)w * h;
     const size_t p = blockIdx.z;
-    const float *R0 = R + p * fstep * 5 * npx;
-    const float *R1 = R0 + 5 * npx;
+    const float *R0 = R + p * fstep * r_frame_stride(npx);
+    const float *R1 = R0 + r_frame_stride(npx);
     const float2 *fin = MODE == 2 ? flow_in + p * npx : nullptr;
     float2 *fout = flow_out + p * npx;
 
@@ -172,10 +191,20 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
     int buf = 0;
     int j = 0;                               // offset of padded row t in its block (uniform)
 
+#ifdef OFARN_STAMPS
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+#endif
     auto do_row = [&](const int step, GatherRaw &raw, FlowRaw &fr) {
         const int t = y0 + step;
         float m[5], old[5];
+        STAMP(7);
+#ifdef OFARN_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // attribute the whole load wait to segment 0
+#endif
+        STAMP(0);
         matrices_finish(raw, w, h, xc, row_of(t - M_), m);
+        STAMP(1);
         {
             // vmcnt counts loads in issue order: the flow load goes FIRST in every step so that the
             // wait for it (two steps later) does not also wait for the younger gathers behind it.
@@ -187,6 +216,7 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
             gather_issue(R0, R1, npx, w, h, xc, row_of(t + 1 - M_), dx, dy, raw);
             __builtin_amdgcn_sched_barrier(0);
         }
+        STAMP(2);
 #if OFARN_ABLATE == 8      /* memory pattern only: loads + trivial ALU + store of the INPUT flow */
         {
             float acc = 0.f;
@@ -223,9 +253,11 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
             if (emit) sV[buf][c][tid] = V;
         }
         j = j + 1 == B ? 0 : j + 1;
+        STAMP(3);
         if (!emit) return;
         const int y = t - (B - 1);
         barrier_lds_only();
+        STAMP(4);
         if (tid >= M_ && tid < FI_THREADS - M_ && x < w) {
             double g[5];
 #pragma unroll
@@ -254,16 +286,22 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
                 g[c] = s2 * scale;
 #endif
             }
+            STAMP(5);
             const double idet = 1. / (g[0] * g[2] - g[1] * g[1] + 1e-3);
             float2 o;
             o.x = (float)((g[0] * g[4] - g[1] * g[3]) * idet);
             o.y = (float)((g[2] * g[3] - g[1] * g[4]) * idet);
             stg_f2(fout, ((unsigned)y * (unsigned)w + (unsigned)x) * 8u, o);
         }
+        STAMP(6);
         buf ^= 1;
     };
 
     for (int step = 0; step < nsteps; step++) do_row(step, rawA, frA);
+#ifdef OFARN_STAMPS
+    if (up.dbg && (tid & 63) == 0)
+        for (int k = 0; k < 8; k++) atomicAdd(up.dbg + k, seg[k]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -294,7 +332,7 @@ __global__ __launch_bounds__(FI_THREADS) void k_polyexp_march(const void *__rest
     const size_t npx = (size_t)w * h;
     const float *img = SRC == 0 ? reinterpret_cast<const float *>(src) + (size_t)blockIdx.z * src_stride : nullptr;
     const uint8_t *frm = SRC == 1 ? reinterpret_cast<const uint8_t *>(src) + (size_t)blockIdx.z * src_stride : nullptr;
-    float *out = R + (size_t)blockIdx.z * 5 * npx;
+    float *out = R + (size_t)blockIdx.z * r_frame_stride(npx);
 
     // level-0 source: 3-tap blur state for this column (row pass of rows yy-1, yy, yy+1)
     const int xl = reflect101(xc - 1, w), xr = reflect101(xc + 1, w);
@@ -359,12 +397,9 @@ __global__ __launch_bounds__(FI_THREADS) void k_polyexp_march(const void *__rest
                 b6 += (p1[k] - p1[-k]) * xgk;
                 b5 += (p2[k] + p2[-k]) * gk;
             }
-            const size_t o = (size_t)y * w + x;
-            out[o] = (float)(b3 * c.ig11);
-            out[npx + o] = (float)(b2 * c.ig11);
-            out[2 * npx + o] = (float)(b1 * c.ig03 + b5 * c.ig33);
-            out[3 * npx + o] = (float)(b1 * c.ig03 + b4 * c.ig33);
-            out[4 * npx + o] = (float)(b6 * c.ig55);
+            const float rv[5] = {(float)(b3 * c.ig11), (float)(b2 * c.ig11), (float)(b1 * c.ig03 + b5 * c.ig33),
+                                 (float)(b1 * c.ig03 + b4 * c.ig33), (float)(b6 * c.ig55)};
+            store_r(out, npx, (unsigned)y * (unsigned)w + (unsigned)x, rv);
         }
         buf ^= 1;
     }
@@ -410,7 +445,65 @@ __global__ __launch_bounds__(256) void k_level_hpass_lds(const uint8_t *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_level_hpass_multi: stage A pass 1 for ALL levels >= 1 in one launch.  One block per frame row:
+// the uint8 row is read once, converted and staged in LDS with a reflect-101 border of the widest
+// kernel, then every level's sampled columns are filtered out of LDS (same arithmetic and order
+// as k_level_hpass).  Work item = (level, level column, left/right source column).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_level_hpass_multi(const uint8_t *__restrict__ frames, size_t frame_stride,
+                                                            int W, int H, HLevels L)
+{
+    extern __shared__ float srow[];
+    const int y = blockIdx.y;
+    const uint8_t *row = frames + (size_t)blockIdx.z * frame_stride + (size_t)y * W;
+    const int tid = threadIdx.x;
+    const int rmax = L.rmax, ext = W + 2 * rmax;
+    float *sk = srow + skew(ext) + 1;        // all levels' kernel taps, back to back
+    for (int i = tid; i < ext; i += 256) srow[skew(i)] = (float)row[reflect101(i - rmax, W)];
+    {
+        int off = 0;
+        for (int l = 0; l < L.n; l++) {
+            for (int i = tid; i < L.lv[l].ksize; i += 256) sk[off + i] = L.lv[l].kern[i];
+            off += L.lv[l].ksize;
+        }
+    }
+    __syncthreads();
+    int koff = 0;
+    for (int l = 0; l < L.n; l++) {
+        const HLevel lv = L.lv[l];
+        const int r = lv.ksize >> 1;
+        const float *kk = sk + koff;
+        koff += lv.ksize;
+        float2 *dst = reinterpret_cast<float2 *>(lv.dst) + ((size_t)blockIdx.z * H + y) * lv.dw;
+        for (int dx = tid; dx < lv.dw; dx += 256) {
+            const int sx = lv.xofs[dx];
+            const int p = sx - r + rmax;             // extended index of tap 0 of the left column
+            float acc0, acc1;
+            if (sx + 1 < W) {
+                // right column = left column + 1: its tap t reads what the left column's tap t+1 reads
+                float v0 = srow[skew(p)], v1 = srow[skew(p + 1)];
+                acc0 = kk[0] * v0;
+                acc1 = kk[0] * v1;
+                for (int t = 1; t < lv.ksize; t++) {
+                    v0 = v1;
+                    v1 = srow[skew(p + t + 1)];
+                    const float f = kk[t];
+                    acc0 = acc0 + f * v0;
+                    acc1 = acc1 + f * v1;
+                }
+            } else {                                 // clamped: both columns are W-1
+                acc0 = kk[0] * srow[skew(p)];
+                for (int t = 1; t < lv.ksize; t++) acc0 = acc0 + kk[t] * srow[skew(p + t)];
+                acc1 = acc0;
+            }
+            dst[dx] = make_float2(acc0, acc1);
+        }
+    }
+}
+
 static inline unsigned cdivu(int a, int b) { return (unsigned)((a + b - 1) / b); }
+int best_strip_units(int nunits, int unit, int warm, int blocks_per_strip_row, int blocks_per_cu);
 
 bool flow_iter_supported(int winsize) { return winsize / 2 == 7; }
 
@@ -422,15 +515,30 @@ void launch_flow_iter(hipStream_t s, const float *R, int fstep, const float *flo
     constexpr int M_ = 7;
     constexpr int OUTW = FI_THREADS - 2 * M_;
     constexpr int B = 2 * M_ + 1;
-    // strips start on block boundaries of the blocked column sums (multiples of B rows)
+    // strips start on block boundaries of the blocked column sums (multiples of B rows); their
+    // number is chosen to minimise (rounds of resident blocks) x (rows marched per block)
     const int nblk = (h + B - 1) / B;
-    int nstrips = (h + 64) / 128;
-    if (nstrips < 1) nstrips = 1;
-    if (nstrips > nblk) nstrips = nblk;
-    const int strip_h = ((nblk + nstrips - 1) / nstrips) * B;
+    const int strip_h = B * best_strip_units(nblk, B, B - 1, (int)cdivu(w, OUTW) * npairs, 3);
     dim3 grid(cdivu(w, OUTW), cdivu(h, strip_h), npairs);
     const double scale = 1. / ((double)winsize * winsize);
-    UpsampleArgs up{reinterpret_cast<const float2 *>(coarse), cw, ch, d_xofs, d_xa, d_yofs, d_ya, mul};
+    UpsampleArgs up{reinterpret_cast<const float2 *>(coarse), cw, ch, d_xofs, d_xa, d_yofs, d_ya, mul, nullptr};
+#ifdef OFARN_STAMPS
+    static unsigned long long *dbg = nullptr;
+    static int calls = 0;
+    if (!dbg) { (void)hipMalloc((void **)&dbg, 64); (void)hipMemset(dbg, 0, 64); }
+    up.dbg = dbg;
+    if (++calls % 9 == 0 && w >= 1920) {
+        unsigned long long hbuf[8];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(hbuf, dbg, 64, hipMemcpyDeviceToHost);
+        double tot = 0;
+        for (int k = 0; k < 8; k++) tot += (double)hbuf[k];
+        fprintf(stderr, "[stamps] wait-loads %.1f%% matrices %.1f%% issue %.1f%% colsum+ldsw %.1f%% barrier %.1f%% hsum %.1f%% solve+store %.1f%% loop-ovh %.1f%%\n",
+                100 * hbuf[0] / tot, 100 * hbuf[1] / tot, 100 * hbuf[2] / tot, 100 * hbuf[3] / tot, 100 * hbuf[4] / tot,
+                100 * hbuf[5] / tot, 100 * hbuf[6] / tot, 100 * hbuf[7] / tot);
+        (void)hipMemset(dbg, 0, 64);
+    }
+#endif
     const float2 *fin = reinterpret_cast<const float2 *>(flow_in);
     float2 *fout = reinterpret_cast<float2 *>(flow_out);
     if (mode == 0)
@@ -445,11 +553,28 @@ void launch_flow_iter(hipStream_t s, const float *R, int fstep, const float *flo
 
 namespace ofarn {
 
-static inline int pick_strip(int h)
+// Strip height in `unit`-row steps for a marching kernel: each block marches strip + warm rows, the
+// GPU holds blocks_per_cu * CUs blocks at once; minimise ceil(blocks / resident) * rows-per-block.
+int best_strip_units(int nunits, int unit, int warm, int blocks_per_strip_row, int blocks_per_cu)
 {
-    int nstrips = (h + 64) / 128;
-    if (nstrips < 1) nstrips = 1;
-    return (h + nstrips - 1) / nstrips;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    const long resident = (long)ncu * blocks_per_cu;
+    long best_cost = -1;
+    int best = nunits;
+    for (int per = 1; per <= nunits; per++) {
+        const int nstrips = (nunits + per - 1) / per;
+        const long blocks = (long)nstrips * blocks_per_strip_row;
+        const long rounds = (blocks + resident - 1) / resident;
+        const long cost = rounds * ((long)per * unit + warm);
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && per > best)) { best_cost = cost; best = per; }
+    }
+    return best;
 }
 
 bool polyexp_march_supported(int poly_n) { return poly_n == 5; }
@@ -460,7 +585,7 @@ void launch_polyexp_march(hipStream_t s, const void *src, size_t src_stride, int
 {
     constexpr int N = 5;
     constexpr int OUTW = FI_THREADS - 2 * N;
-    const int strip_h = pick_strip(h);
+    const int strip_h = best_strip_units(h, 1, 2 * N, (int)cdivu(w, OUTW) * nframes, 6);
     dim3 grid(cdivu(w, OUTW), cdivu(h, strip_h), nframes);
     if (src_is_u8)
         hipLaunchKernelGGL((k_polyexp_march<N, 1>), grid, dim3(FI_THREADS), 0, s, src, src_stride, R, w, h, strip_h, c,
@@ -479,6 +604,24 @@ void launch_level_hpass_lds(hipStream_t s, const uint8_t *frames, size_t frame_s
     dim3 grid(1, H, nframes);
     hipLaunchKernelGGL(k_level_hpass_lds, grid, dim3(256), lds, s, frames, frame_stride, W, H, d_kern, ksize, d_xofs,
                        dw, reinterpret_cast<float2 *>(tmp));
+}
+
+}  // namespace ofarn
+
+namespace ofarn {
+
+size_t hpass_multi_lds_bytes(int W, int rmax)
+{
+    const int ext = W + 2 * rmax;
+    return sizeof(float) * (size_t)(ext + (ext >> 5) + 2 + 12 * (2 * rmax + 1));   // row + taps of <= 12 levels
+}
+
+void launch_level_hpass_multi(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
+                              const HLevels &L)
+{
+    dim3 grid(1, H, nframes);
+    hipLaunchKernelGGL(k_level_hpass_multi, grid, dim3(256), hpass_multi_lds_bytes(W, L.rmax), s, frames, frame_stride,
+                       W, H, L);
 }
 
 }  // namespace ofarn

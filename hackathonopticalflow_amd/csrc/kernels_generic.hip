@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, fl
         sR0[i] = r0; sR1[i] = r1; sR2[i] = r2;
     }
     __syncthreads();
-    float *out = R + (size_t)blockIdx.z * 5 * npx;
+    float *out = R + (size_t)blockIdx.z * r_frame_stride(npx);
     for (int i = tid; i < PE_TH * PE_TW; i += 256) {
         const int ly = i / PE_TW, ox = i - ly * PE_TW;
         const int gx = x0 + ox, gy = y0 + ly;
@@ -146,12 +146,9 @@ __global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, fl
             b6 += (p1[k] - p1[-k]) * xgk;
             b5 += (p2[k] + p2[-k]) * gk;
         }
-        const size_t o = (size_t)gy * w + gx;
-        out[o] = (float)(b3 * c.ig11);
-        out[npx + o] = (float)(b2 * c.ig11);
-        out[2 * npx + o] = (float)(b1 * c.ig03 + b5 * c.ig33);
-        out[3 * npx + o] = (float)(b1 * c.ig03 + b4 * c.ig33);
-        out[4 * npx + o] = (float)(b6 * c.ig55);
+        const float rv[5] = {(float)(b3 * c.ig11), (float)(b2 * c.ig11), (float)(b1 * c.ig03 + b5 * c.ig33),
+                             (float)(b1 * c.ig03 + b4 * c.ig33), (float)(b6 * c.ig55)};
+        store_r(out, npx, (unsigned)gy * (unsigned)w + (unsigned)gx, rv);
     }
 }
 
@@ -195,8 +192,8 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
     if (x >= w) return;
     const size_t npx = (size_t)w * h;
     const size_t p = blockIdx.z;
-    const float *R0 = R + p * fstep * 5 * npx;
-    const float *R1 = R0 + 5 * npx;
+    const float *R0 = R + p * fstep * r_frame_stride(npx);
+    const float *R1 = R0 + r_frame_stride(npx);
     const float2 d = flow[p * npx + (size_t)y * w + x];
     float m[5];
     update_matrices_px(R0, R1, npx, w, h, x, y, d.x, d.y, m);

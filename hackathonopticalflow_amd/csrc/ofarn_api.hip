@@ -223,6 +223,7 @@ struct ofarn_ctx {
     // workspace
     float *tmp = nullptr, *I = nullptr, *R = nullptr, *M = nullptr, *flowA = nullptr, *flowB = nullptr;
     uint64_t ws_bytes = 0;
+    size_t tmp_floats = 0;   // capacity of tmp in floats
     // host-API staging (lazy)
     uint8_t *st_frames = nullptr;
     float *st_flow = nullptr;
@@ -343,6 +344,31 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
     float *prev = nullptr;
     int pw = 0, ph = 0;
     const bool fused = !c->force_generic && c->prm.iterations >= 1 && flow_iter_supported(c->prm.winsize);
+    // Row pass of the level build for all levels that need one, in a single launch when their
+    // tmp buffers fit side by side in the workspace; tmp_of[k] is where level k's rows went.
+    const bool march0 = !c->force_generic && polyexp_march_supported(c->prm.poly_n);
+    float *tmp_of[32] = {nullptr};
+    if (!c->force_generic) {
+        HLevels HL{};
+        size_t off = 0;
+        bool ok = true;
+        for (int k = nlev; k >= 0 && ok; k--) {
+            const Level &L = c->lv[k];
+            if (march0 && L.w == w && L.h == h && L.ksize == 3) continue;   // fused into the poly expansion
+            const size_t need = (size_t)nframes * h * L.w * 2;
+            if (HL.n >= 12 || off + need > c->tmp_floats) { ok = false; break; }
+            HL.lv[HL.n++] = HLevel{L.d_kern, L.d_xofs, c->tmp + off, L.w, L.ksize};
+            if (L.ksize / 2 > HL.rmax) HL.rmax = L.ksize / 2;
+            tmp_of[k] = c->tmp + off;
+            off += need;
+        }
+        if (ok && HL.n > 0 && hpass_multi_lds_bytes(w, HL.rmax) <= 60 * 1024) {
+            double units = 0;
+            for (int i = 0; i < HL.n; i++) units += (double)HL.lv[i].dw * h * nframes;
+            timed(c, s, OFARN_STAGE_LEVEL_H, 31, units, [&] { launch_level_hpass_multi(s, d_frames, fsz, w, h, nframes, HL); });
+        } else
+            for (auto &t : tmp_of) t = nullptr;
+    }
     for (int k = nlev; k >= 0; k--) {
         const Level &L = c->lv[k];
         const size_t npx = (size_t)L.w * L.h;
@@ -357,14 +383,16 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
                 launch_polyexp_march(s, d_frames, fsz, 1, c->R, L.w, L.h, nframes, c->poly, L.h_kern3);
             });
         } else {
-            timed(c, s, OFARN_STAGE_LEVEL_H, k, ufr, [&] {
-                if (!c->force_generic && lds_ok)
-                    launch_level_hpass_lds(s, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, c->tmp);
-                else
-                    launch_level_hpass(s, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, c->tmp);
-            });
+            float *tmpk = tmp_of[k] ? tmp_of[k] : c->tmp;
+            if (!tmp_of[k])
+                timed(c, s, OFARN_STAGE_LEVEL_H, k, ufr, [&] {
+                    if (!c->force_generic && lds_ok)
+                        launch_level_hpass_lds(s, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, c->tmp);
+                    else
+                        launch_level_hpass(s, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, c->tmp);
+                });
             timed(c, s, OFARN_STAGE_LEVEL_V, k, ufr, [&] {
-                launch_level_vpass(s, c->tmp, h, L.w, L.h, nframes, L.d_kern, L.ksize, L.d_xa, L.d_yofs, L.d_ya, c->I);
+                launch_level_vpass(s, tmpk, h, L.w, L.h, nframes, L.d_kern, L.ksize, L.d_xa, L.d_yofs, L.d_ya, c->I);
             });
             timed(c, s, OFARN_STAGE_POLYEXP, k, ufr, [&] {
                 if (march) launch_polyexp_march(s, c->I, npx, 0, c->R, L.w, L.h, nframes, c->poly, L.h_kern3);
@@ -496,8 +524,9 @@ int ofarn_create(const ofarn_params *params, int device, int max_w, int max_h, i
     const size_t px = (size_t)max_w * max_h;
     const size_t F = (size_t)2 * max_batch, Pn = (size_t)max_batch;
     struct { float **p; size_t n; } req[] = {
-        {&c->tmp, F * px * 2}, {&c->I, F * px}, {&c->R, F * px * 5}, {&c->M, Pn * px * 5},
+        {&c->tmp, F * px * 2}, {&c->I, F * px}, {&c->R, F * (px * 5 + 4)}, {&c->M, Pn * px * 5},
         {&c->flowA, Pn * px * 2}, {&c->flowB, Pn * px * 2}};
+    c->tmp_floats = F * px * 2;
     for (auto &r : req) {
         const size_t bytes = r.n * sizeof(float) + 256;
         if (hipMalloc((void **)r.p, bytes) != hipSuccess)
@@ -764,6 +793,23 @@ int ofarn_stage_level_image(ofarn_ctx *c, const uint8_t *h_img, int w, int h, in
     return OFARN_OK;
 }
 
+// host <-> device layout helpers of the single-stage entry points (test-only paths)
+static void r_to_device_layout(const float *h_il, size_t npx, std::vector<float> &dev)   // [npx][5] -> 4+1
+{
+    dev.assign(r_frame_stride(npx), 0.f);
+    for (size_t o = 0; o < npx; o++) {
+        for (int ch = 0; ch < 4; ch++) dev[o * 4 + ch] = h_il[o * 5 + ch];
+        dev[4 * npx + o] = h_il[o * 5 + 4];
+    }
+}
+static void r_from_device_layout(const std::vector<float> &dev, size_t npx, float *h_il)
+{
+    for (size_t o = 0; o < npx; o++) {
+        for (int ch = 0; ch < 4; ch++) h_il[o * 5 + ch] = dev[o * 4 + ch];
+        h_il[o * 5 + 4] = dev[4 * npx + o];
+    }
+}
+
 int ofarn_stage_polyexp(ofarn_ctx *c, const float *h_img, int w, int h, float *h_R)
 {
     int rc = check_size(c, w, h);
@@ -777,8 +823,10 @@ int ofarn_stage_polyexp(ofarn_ctx *c, const float *h_img, int w, int h, float *h
         launch_polyexp_march(c->stream, c->I, npx, 0, c->R, w, h, 1, c->poly, none);
     } else
         launch_polyexp(c->stream, c->I, c->R, w, h, 1, c->poly);
-    HIP_TRY(hipMemcpyAsync(h_R, c->R, npx * 5 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    std::vector<float> dev(r_frame_stride(npx));
+    HIP_TRY(hipMemcpyAsync(dev.data(), c->R, dev.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    r_from_device_layout(dev, npx, h_R);
     return OFARN_OK;
 }
 
@@ -790,12 +838,18 @@ int ofarn_stage_update_matrices(ofarn_ctx *c, const float *h_R0, const float *h_
     if (!h_R0 || !h_R1 || !h_flow || !h_M) return fail(OFARN_E_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
     const size_t npx = (size_t)w * h;
-    HIP_TRY(hipMemcpyAsync(c->R, h_R0, npx * 5 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->R + npx * 5, h_R1, npx * 5 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    std::vector<float> d0, d1;
+    r_to_device_layout(h_R0, npx, d0);
+    r_to_device_layout(h_R1, npx, d1);
+    HIP_TRY(hipMemcpyAsync(c->R, d0.data(), d0.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->R + r_frame_stride(npx), d1.data(), d1.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->flowA, h_flow, npx * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    launch_update_matrices(c->stream, c->R, 2, c->flowA, c->M, w, h, 1);
-    HIP_TRY(hipMemcpyAsync(h_M, c->M, npx * 5 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    launch_update_matrices(c->stream, c->R, 1, c->flowA, c->M, w, h, 1);
+    std::vector<float> mp(npx * 5);
+    HIP_TRY(hipMemcpyAsync(mp.data(), c->M, npx * 5 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (size_t o = 0; o < npx; o++)
+        for (int ch = 0; ch < 5; ch++) h_M[o * 5 + ch] = mp[ch * npx + o];     // planar -> interleaved
     return OFARN_OK;
 }
 
@@ -806,7 +860,10 @@ int ofarn_stage_blur_solve(ofarn_ctx *c, const float *h_M, int w, int h, float *
     if (!h_M || !h_flow) return fail(OFARN_E_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
     const size_t npx = (size_t)w * h;
-    HIP_TRY(hipMemcpyAsync(c->M, h_M, npx * 5 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    std::vector<float> mp(npx * 5);
+    for (size_t o = 0; o < npx; o++)
+        for (int ch = 0; ch < 5; ch++) mp[ch * npx + o] = h_M[o * 5 + ch];     // interleaved -> planar
+    HIP_TRY(hipMemcpyAsync(c->M, mp.data(), npx * 5 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     launch_blur_solve(c->stream, c->M, c->flowA, w, h, 1, c->prm.winsize);
     HIP_TRY(hipMemcpyAsync(h_flow, c->flowA, npx * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

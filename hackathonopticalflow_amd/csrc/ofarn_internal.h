@@ -5,8 +5,9 @@
 //   tmp      float  [F][H][w_k][2]           row-filtered frame at the two source columns each
 //                                            level column samples (level build, stage A)
 //   I_k      float  [F][h_k][w_k]            level image
-//   R_k      float  [F][5][h_k][w_k]         polynomial expansion, channel-planar
-//                                            (channel order of optflowgf.cpp: y, x, yy, xx, xy)
+//   R_k      per frame 5*h_k*w_k floats      polynomial expansion in the "4+1" layout: channels
+//                                            0..3 of pixel o as float4 [h_k][w_k], then channel 4
+//                                            as float [h_k][w_k] (optflowgf.cpp order y,x,yy,xx,xy)
 //   M_k      float  [P][5][h_k][w_k]         G11, G12, G22, h1, h2, channel-planar
 //   flow_k   float2 [P][h_k][w_k]            (dx, dy)
 // F = frames in the wave, P = pairs in the wave.  Pair p reads frames (2p, 2p+1) or (p, p+1).
@@ -19,6 +20,10 @@ namespace ofarn {
 
 constexpr int kMaxPolyN = 15;
 constexpr int kBorder = 5;   // FarnebackUpdateMatrices: BORDER
+
+// floats between consecutive frames of R (5 per pixel, rounded up so every frame's float4 plane is
+// 16-byte aligned)
+__host__ __device__ inline size_t r_frame_stride(size_t npx) { return (5 * npx + 3) & ~(size_t)3; }
 
 struct PolyCoef {
     float g[kMaxPolyN + 1];
@@ -63,6 +68,20 @@ void launch_polyexp_march(hipStream_t s, const void *src, size_t src_stride, int
 // Stage A pass 1 with the frame row staged in LDS (levels >= 1).
 void launch_level_hpass_lds(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
                             const float *d_kern, int ksize, const int *d_xofs, int dw, float *tmp);
+// Stage A pass 1 for several levels in one launch (kernels_fast.hip): the frame row is read once.
+struct HLevel {
+    const float *kern;   // device, ksize taps
+    const int *xofs;     // device, dw source columns
+    float *dst;          // device, tmp of this level: [F][H][dw][2]
+    int dw, ksize;
+};
+struct HLevels {
+    HLevel lv[12];
+    int n, rmax;
+};
+size_t hpass_multi_lds_bytes(int W, int rmax);
+void launch_level_hpass_multi(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
+                              const HLevels &L);
 // Stage F: grid sample + vector filter + danger brightness.  d_pts int2[P] grid coordinates.
 int grid_filter_lds_bytes(int P);
 void launch_grid_filter(hipStream_t s, const float *flow, int w, int h, int npairs, const int *d_pts,

@@ -324,7 +324,7 @@ class FarnebackEngine:
     def stage_polyexp(self, I):
         I = np.ascontiguousarray(I, np.float32)
         h, w = I.shape
-        R = np.empty((5, h, w), np.float32)
+        R = np.empty((h, w, 5), np.float32)
         _check(self._lib.ofarn_stage_polyexp(self._h, I.ctypes.data_as(_fp), w, h, R.ctypes.data_as(_fp)))
         return R
 
@@ -332,14 +332,14 @@ class FarnebackEngine:
         R0, R1 = np.ascontiguousarray(R0, np.float32), np.ascontiguousarray(R1, np.float32)
         flow = np.ascontiguousarray(flow, np.float32)
         h, w = flow.shape[:2]
-        M = np.empty((5, h, w), np.float32)
+        M = np.empty((h, w, 5), np.float32)
         _check(self._lib.ofarn_stage_update_matrices(self._h, R0.ctypes.data_as(_fp), R1.ctypes.data_as(_fp),
                                                      flow.ctypes.data_as(_fp), w, h, M.ctypes.data_as(_fp)))
         return M
 
     def stage_blur_solve(self, M):
         M = np.ascontiguousarray(M, np.float32)
-        _, h, w = M.shape
+        h, w, _ = M.shape
         flow = np.empty((h, w, 2), np.float32)
         _check(self._lib.ofarn_stage_blur_solve(self._h, M.ctypes.data_as(_fp), w, h, flow.ctypes.data_as(_fp)))
         return flow

@@ -133,8 +133,9 @@ uint64_t ofarn_workspace_bytes(const ofarn_ctx *ctx);
 const char *ofarn_version(void);
 
 /* ---- single-stage entry points (host arrays in/out, one image; used by the parity tests to
- * compare each HIP kernel with the oracle stage by stage).  Channel-planar float32 [5][h][w]
- * for R and M; interleaved float32 [h][w][2] for flow. -------------------------------------- */
+ * compare each HIP kernel with the oracle stage by stage).  R and M are exchanged as interleaved
+ * float32 [h][w][5] (OpenCV's CV_32FC5 order; the device-internal layouts differ), flow as
+ * interleaved float32 [h][w][2]. -------------------------------------- */
 int ofarn_stage_level_image(ofarn_ctx *ctx, const uint8_t *h_img, int w, int h, int k, float *h_out);
 int ofarn_stage_polyexp(ofarn_ctx *ctx, const float *h_img, int w, int h, float *h_R);
 int ofarn_stage_update_matrices(ofarn_ctx *ctx, const float *h_R0, const float *h_R1,

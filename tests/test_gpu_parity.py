@@ -31,10 +31,6 @@ def H():
     return H
 
 
-def planar(a):   # oracle [h,w,5] -> device layout [5,h,w]
-    return np.ascontiguousarray(np.moveaxis(a, -1, 0))
-
-
 def epe(a, b):
     return np.linalg.norm(a.astype(np.float64) - b.astype(np.float64), axis=-1)
 
@@ -57,7 +53,7 @@ def test_stage_polyexp_bit_exact(H, oracle, w, h, n, sigma):
     I = rng.uniform(0, 255, (h, w)).astype(np.float32)
     with H.FarnebackEngine(w, h, 1, poly_n=n, poly_sigma=sigma) as eng:
         got = eng.stage_polyexp(I)
-    np.testing.assert_array_equal(got, planar(oracle.polyexp(I, n, sigma)))
+    np.testing.assert_array_equal(got, oracle.polyexp(I, n, sigma))
 
 
 @pytest.mark.parametrize("w,h", [(320, 240), (97, 83), (33, 40)])
@@ -70,8 +66,8 @@ def test_stage_update_matrices_bit_exact(H, oracle, w, h):
     flow[-1, -5:] = 9
     flow[5, 5] = (0.0, 0.0)
     with H.FarnebackEngine(w, h, 1) as eng:
-        got = eng.stage_update_matrices(planar(R0), planar(R1), flow)
-    np.testing.assert_array_equal(got, planar(oracle.update_matrices(R0, R1, flow)))
+        got = eng.stage_update_matrices(R0, R1, flow)
+    np.testing.assert_array_equal(got, oracle.update_matrices(R0, R1, flow))
 
 
 @pytest.mark.parametrize("w,h,winsize", [(320, 240, 15), (97, 83, 9), (70, 50, 8), (40, 33, 3), (64, 48, 41),
@@ -82,7 +78,7 @@ def test_stage_blur_solve_bit_exact(H, oracle, w, h, winsize):
     z5, z2 = np.zeros((h, w, 5), np.float32), np.zeros((h, w, 2), np.float32)
     ref, _ = oracle.update_flow_blur(z5, z5, z2, M, winsize, False, oracle.BOX_BLOCKED)
     with H.FarnebackEngine(w, h, 1, winsize=winsize) as eng:
-        got = eng.stage_blur_solve(planar(M))
+        got = eng.stage_blur_solve(M)
     np.testing.assert_array_equal(got, ref)
 
 
@@ -124,7 +120,7 @@ def test_stage_kernels_generic_variants(H, oracle, monkeypatch):
     rng = np.random.default_rng(1)
     I = rng.uniform(0, 255, (83, 300)).astype(np.float32)
     with H.FarnebackEngine(300, 83, 1) as eng:
-        np.testing.assert_array_equal(eng.stage_polyexp(I), planar(oracle.polyexp(I, 5, 1.2)))
+        np.testing.assert_array_equal(eng.stage_polyexp(I), oracle.polyexp(I, 5, 1.2))
     img, _, _ = translated_pair(251, 333, 7)
     with H.FarnebackEngine(333, 251, 1, levels=2) as eng:
         for k, (lw, lh, ks, sg) in enumerate(H.level_plan(333, 251, levels=2)):
