@@ -1,0 +1,88 @@
+"""Shard arithmetic and the danger-map gather, on CPU: fake communicator + 2 gloo ranks."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from hackathonopticalflow_amd import distributed as D
+from hackathonopticalflow_amd.ofarn import PAIRS_CONSECUTIVE, PAIRS_INDEPENDENT
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("n,world", [(512, 8), (64, 8), (10, 4), (3, 8), (0, 2), (7, 1)])
+def test_shard_pairs_partition(n, world):
+    spans = [D.shard_pairs(n, r, world) for r in range(world)]
+    assert spans[0][0] == 0
+    for (s0, c0), (s1, _) in zip(spans, spans[1:]):
+        assert s1 == s0 + c0            # contiguous
+    assert sum(c for _, c in spans) == n
+    counts = [c for _, c in spans]
+    assert max(counts) - min(counts) <= 1
+
+
+def test_shard_frames_modes():
+    # video order: neighbouring ranks overlap by one frame (DenseOF.py:525)
+    s0 = D.shard_frames(9, PAIRS_CONSECUTIVE, 0, 2)
+    s1 = D.shard_frames(9, PAIRS_CONSECUTIVE, 1, 2)
+    assert (s0.pair_start, s0.pair_count, s0.frame_start, s0.frame_count) == (0, 4, 0, 5)
+    assert (s1.pair_start, s1.pair_count, s1.frame_start, s1.frame_count) == (4, 4, 4, 5)
+    s = D.shard_frames(16, PAIRS_INDEPENDENT, 3, 4)
+    assert (s.pair_start, s.pair_count, s.frame_start, s.frame_count) == (6, 2, 12, 4)
+    with pytest.raises(ValueError):
+        D.shard_frames(15, PAIRS_INDEPENDENT, 0, 2)
+    assert D.shard_frames(1, PAIRS_CONSECUTIVE, 0, 2).frame_count == 0
+
+
+def test_fake_communicator_gather_order():
+    world, n, P = 3, 8, 11
+    rng = np.random.default_rng(0)
+    full_m = rng.integers(0, 2, (n, P)).astype(np.uint8)
+    full_v = rng.integers(0, 256, (n, P)).astype(np.uint8)
+    parts_m, parts_v = [], []
+    for r in range(world):
+        s, c = D.shard_pairs(n, r, world)
+        parts_m.append(full_m[s:s + c])
+        parts_v.append(full_v[s:s + c])
+    m, v = D.FakeCommunicator(world).gather(parts_m, parts_v, n)
+    np.testing.assert_array_equal(m, full_m)
+    np.testing.assert_array_equal(v, full_v)
+
+
+def _worker(rank, world, port, n_pairs, P, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch
+    from hackathonopticalflow_amd import distributed as DD
+    dist = DD.init_process_group("gloo")
+    s, c = DD.shard_pairs(n_pairs, rank, world)
+    rng = np.random.default_rng(123)
+    full_m = rng.integers(0, 2, (n_pairs, P)).astype(np.uint8)
+    full_v = rng.integers(0, 256, (n_pairs, P)).astype(np.uint8)
+    m, v = DD.gather_danger_maps(torch.from_numpy(full_m[s:s + c].copy()), torch.from_numpy(full_v[s:s + c].copy()),
+                                 n_pairs, dist)
+    ok = np.array_equal(m.numpy(), full_m) and np.array_equal(v.numpy(), full_v)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+@pytest.mark.parametrize("n_pairs", [8, 5])
+def test_gather_danger_maps_two_gloo_ranks(n_pairs):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_pairs, 352, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]

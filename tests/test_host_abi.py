@@ -1,0 +1,96 @@
+"""CPU-side checks of the product's host logic and C-ABI (no GPU, no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import hackathonopticalflow_amd as H
+from hackathonopticalflow_amd import ofarn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ofarn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ofarn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = H.load_library()
+    syms = _declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"libofarn.so does not export {s}"
+        assert s in ofarn.ABI, f"{s} is declared in include/ofarn.h but not bound in ofarn.py"
+    assert set(ofarn.ABI) == set(syms)
+    assert b"gfx950" in lib.ofarn_version()
+
+
+def test_default_params_match_reference_defaults():
+    # DenseOF.py:127-128 keyword defaults, pathfinder_viewer.py:16 step
+    p = H.OfarnParams()
+    H.load_library().ofarn_default_params(ctypes.byref(p))
+    assert (p.pyr_scale, p.levels, p.winsize, p.iterations, p.poly_n, p.poly_sigma, p.flags, p.grid_step) == \
+        (0.5, 3, 15, 3, 5, 1.2, 0, 30)
+
+
+@pytest.mark.parametrize("w,h,kw", [(1920, 1080, dict(levels=5)), (3840, 2160, dict(levels=6)), (640, 480, {}),
+                                    (640, 480, dict(levels=10)), (97, 83, dict(levels=2)),
+                                    (1000, 700, dict(levels=4, pyr_scale=0.8))])
+def test_level_plan_matches_oracle_geometry(oracle, w, h, kw):
+    plan = H.level_plan(w, h, **kw)
+    ps = kw.get("pyr_scale", 0.5)
+    nlev = oracle.crop_levels(w, h, ps, kw.get("levels", 3))
+    assert len(plan) == nlev + 1          # levels+1 scales
+    for k, (lw, lh, ks, sg) in enumerate(plan):
+        assert (lw, lh, sg, ks) == oracle.level_geom(w, h, ps, k)
+
+
+@pytest.mark.parametrize("w,h,step", [(1920, 1080, 30), (640, 480, 30), (3840, 2160, 30), (1000, 700, 14), (641, 479, 25)])
+def test_grid_points_match_reference_numpy(oracle, w, h, step):
+    np.testing.assert_array_equal(H.grid_points(w, h, step), oracle.grid_points_numpy(w, h, step))
+
+
+def test_parameter_validation_without_gpu():
+    lib = H.load_library()
+    cap = 8
+    arr = (ctypes.c_int * cap)()
+    for bad in (dict(pyr_scale=1.0), dict(pyr_scale=0.0), dict(winsize=1), dict(winsize=500), dict(poly_n=0),
+                dict(poly_n=99), dict(levels=-1), dict(iterations=-1)):
+        p = H.make_params(**bad)
+        assert lib.ofarn_level_plan(ctypes.byref(p), 640, 480, cap, arr, arr, arr, None) == ofarn.OFARN_E_INVALID
+        assert lib.ofarn_last_error()
+    p = H.make_params(flags=4)
+    assert lib.ofarn_level_plan(ctypes.byref(p), 640, 480, cap, arr, arr, arr, None) == ofarn.OFARN_E_UNSUPPORTED
+
+
+def test_input_validation_before_any_device_call():
+    a = np.zeros((64, 64), np.uint8)
+    with pytest.raises(ValueError):
+        H.calculate_optical_flow(a, np.zeros((64, 65), np.uint8))
+    with pytest.raises(ValueError):
+        H.calculate_optical_flow(a.astype(np.float32), a)
+    with pytest.raises(ValueError):
+        H.calculate_optical_flow(np.zeros((64, 64, 3), np.uint8), a)
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU the product must fail loudly (RuntimeError from the HIP runtime), never compute."""
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    a = np.zeros((64, 64), np.uint8)
+    with pytest.raises(RuntimeError):
+        H.calculate_optical_flow(a, a)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "hackathonopticalflow_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "from oracle" not in txt and "import oracle" not in txt and "libofarn_oracle" not in txt, f

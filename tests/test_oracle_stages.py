@@ -281,12 +281,30 @@ def test_translation_ground_truth_640x480(oracle, seed):
     assert epe.mean() < 0.1, (tx, ty, epe.mean())
 
 
-def test_running_and_direct_box_orders_agree(oracle):
+def test_box_summation_orders_agree(oracle):
+    """OpenCV's literal running sums, plain direct sums and the block-restarted running sums the
+    HIP kernels use are the same window in a different order of double additions."""
     p, n, _ = translated_pair(200, 260, 21)
     a = oracle.farneback(p, n, levels=2, box_mode=oracle.BOX_RUNNING)
     b = oracle.farneback(p, n, levels=2, box_mode=oracle.BOX_DIRECT)
-    d = np.linalg.norm(a - b, axis=-1)
-    assert d.mean() < 1e-5 and d.max() < 1e-3
+    c = oracle.farneback(p, n, levels=2, box_mode=oracle.BOX_BLOCKED)
+    for other in (b, c):
+        d = np.linalg.norm(a - other, axis=-1)
+        assert d.mean() < 1e-5 and d.max() < 1e-3
+    d = np.linalg.norm(b - c, axis=-1)
+    assert d.max() < 1e-6
+
+
+@pytest.mark.parametrize("winsize", [2, 3, 8, 15, 41])
+def test_blocked_column_sums_equal_direct_window(oracle, winsize):
+    # values with a short mantissa: every double sum is exact, so the orders must agree bit for bit
+    rng = np.random.default_rng(15)
+    h, w = 67, 45
+    M = (rng.integers(-512, 512, (h, w, 5)) / 8.0).astype(np.float32)
+    z5, z2 = np.zeros_like(M), np.zeros((h, w, 2), np.float32)
+    a, _ = oracle.update_flow_blur(z5, z5, z2, M, winsize, False, oracle.BOX_DIRECT)
+    b, _ = oracle.update_flow_blur(z5, z5, z2, M, winsize, False, oracle.BOX_BLOCKED)
+    np.testing.assert_array_equal(a, b)
 
 
 def test_capture_matches_stage_functions(oracle):
@@ -301,6 +319,26 @@ def test_capture_matches_stage_functions(oracle):
     assert np.all(cap.flow_init[1] == 0)
     up = oracle.resize_linear(cap.flow_out[1], 132, 100) * np.float32(2)
     np.testing.assert_array_equal(cap.flow_init[0], up)
+
+
+def test_golden_fixtures_pin_the_oracle(oracle):
+    """tests/golden/*.npz were written by tests/golden/make_golden.py from this oracle; they keep it
+    from drifting and are what the GPU box compares the HIP path against."""
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+    assert len(files) >= 3
+    for path in files:
+        g = np.load(path, allow_pickle=False)
+        kw = dict(eval(str(g["params"])))
+        np.testing.assert_array_equal(oracle.farneback(g["prev"], g["next"], box_mode=oracle.BOX_BLOCKED, **kw),
+                                      g["flow_direct"])
+        np.testing.assert_array_equal(oracle.farneback(g["prev"], g["next"], box_mode=oracle.BOX_RUNNING, **kw),
+                                      g["flow_running"])
+        h, w = g["prev"].shape
+        mask, v = oracle.danger_map_numpy(g["flow_direct"], w, h, 30)
+        np.testing.assert_array_equal(mask, g["mask"])
+        np.testing.assert_array_equal(v, g["v"])
 
 
 def test_rejects_bad_arguments(oracle):
