@@ -19,14 +19,15 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // just to issue).
 __device__ __forceinline__ void load_r(const float *__restrict__ Rf, size_t npx, unsigned o, float out[5])
 {
-    const float4 a = reinterpret_cast<const float4 *>(Rf)[o];
+    // (uniform base) + (32-bit byte offset): scalar-base addressing, one VGPR per address
+    const float4 a = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Rf) + o * 16u);
     out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
-    out[4] = Rf[4 * npx + o];
+    out[4] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(Rf + 4 * npx) + o * 4u);
 }
 __device__ __forceinline__ void store_r(float *__restrict__ Rf, size_t npx, unsigned o, const float v[5])
 {
-    reinterpret_cast<float4 *>(Rf)[o] = make_float4(v[0], v[1], v[2], v[3]);
-    Rf[4 * npx + o] = v[4];
+    *reinterpret_cast<float4 *>(reinterpret_cast<char *>(Rf) + o * 16u) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(Rf + 4 * npx) + o * 4u) = v[4];
 }
 
 // FarnebackUpdateMatrices for one pixel (optflowgf.cpp), all float32, no FMA contraction.
@@ -133,8 +134,16 @@ __device__ __forceinline__ void gather_issue(const float *__restrict__ R0, const
 // join (s_waitcnt vmcnt(0)), which would also wait for the NEXT rows' prefetched gathers.  The
 // selects and the multiplication by an interior scale of exactly 1.0f leave every bit unchanged.
 __device__ __forceinline__ float border_factor(int i) { return i < 2 ? 0.14f : 0.4472f; }   // BORDER table
+// the four factors of FarnebackUpdateMatrices' border scale, in its order: (x lo)*(x hi)*(y lo)*(y hi)
+__device__ __forceinline__ float border_x(int x, int w)
+{
+    return (x < kBorder ? border_factor(x) : 1.f) * (x >= w - kBorder ? border_factor(w - x - 1) : 1.f);
+}
+__device__ __forceinline__ float border_ylo(int y) { return y < kBorder ? border_factor(y) : 1.f; }
+__device__ __forceinline__ float border_yhi(int y, int h) { return y >= h - kBorder ? border_factor(h - y - 1) : 1.f; }
 
-__device__ __forceinline__ void matrices_finish(const GatherRaw &g, int w, int h, int x, int y, float out[5])
+// bx = border_x(x, w) (a per-thread constant of a marching kernel); y is uniform across the block.
+__device__ __forceinline__ void matrices_finish(const GatherRaw &g, float bx, int h, int y, float out[5])
 {
     const float dx = g.dx, dy = g.dy, fx = g.fx, fy = g.fy;
     const bool inb = g.inb != 0;
@@ -156,8 +165,7 @@ __device__ __forceinline__ void matrices_finish(const GatherRaw &g, int w, int h
     r3 = (g.r0[1] - r3) * 0.5f;
     r2 = r2 + (r4 * dy + r6 * dx);
     r3 = r3 + (r6 * dy + r5 * dx);
-    const float scale = (x < kBorder ? border_factor(x) : 1.f) * (x >= w - kBorder ? border_factor(w - x - 1) : 1.f) *
-                        (y < kBorder ? border_factor(y) : 1.f) * (y >= h - kBorder ? border_factor(h - y - 1) : 1.f);
+    const float scale = (bx * border_ylo(y)) * border_yhi(y, h);
     r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
     out[0] = r4 * r4 + r6 * r6;
     out[1] = (r4 + r5) * r6;

@@ -25,6 +25,7 @@
 #include "ofarn_internal.h"
 
 #include <cstdio>
+#include <type_traits>
 
 namespace ofarn {
 
@@ -103,6 +104,7 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
     const int tid = threadIdx.x;
     const int x = blockIdx.x * OUTW - M_ + tid;
     const int xc = clampi(x, 0, w - 1);
+    const float bx = border_x(xc, w);
     const int y0 = blockIdx.y * strip_h;
     const int y1 = min(y0 + strip_h, h);
     const size_t npx = (size_t)w * h;
@@ -189,13 +191,15 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
 
     const int nsteps = (y1 - y0) + B - 1;   // padded rows y0 .. y1+B-2; output y = t-(B-1)
     int buf = 0;
-    int j = 0;                               // offset of padded row t in its block (uniform)
 
 #ifdef OFARN_STAMPS
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
 #endif
-    auto do_row = [&](const int step, GatherRaw &raw, FlowRaw &fr) {
+    // KIND 0: first row of a block (j == 0), 1: middle rows, 2: last row (j == B-1) -- compile-time so
+    // the P/S updates need no selects.
+    auto do_row = [&](auto kind_c, const int step, const int j, GatherRaw &raw, FlowRaw &fr) {
+        constexpr int KIND = decltype(kind_c)::value;
         const int t = y0 + step;
         float m[5], old[5];
         STAMP(7);
@@ -203,7 +207,7 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // attribute the whole load wait to segment 0
 #endif
         STAMP(0);
-        matrices_finish(raw, w, h, xc, row_of(t - M_), m);
+        matrices_finish(raw, bx, h, row_of(t - M_), m);
         STAMP(1);
         {
             // vmcnt counts loads in issue order: the flow load goes FIRST in every step so that the
@@ -222,7 +226,6 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
             float acc = 0.f;
 #pragma unroll
             for (int c = 0; c < 5; c++) acc += m[c];
-            j = j + 1 == B ? 0 : j + 1;
             if (step >= B - 1 && tid >= M_ && tid < FI_THREADS - M_ && x < w) {
                 float2 o = MODE == 2 ? ldg_f2(fin, ((unsigned)(t - (B - 1)) * (unsigned)w + (unsigned)x) * 8u) : make_float2(0.f, 0.f);
                 o.x += acc * 1e-30f;
@@ -246,13 +249,12 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
             const double V = vn;
 #else
             double V;
-            if (j == 0) P[c] = vn; else P[c] = P[c] + vn;
-            if (j == B - 1) { V = P[c]; S[c] = P[c]; }
+            if constexpr (KIND == 0) P[c] = vn; else P[c] = P[c] + vn;
+            if constexpr (KIND == 2) { V = P[c]; S[c] = P[c]; }
             else { S[c] = S[c] - (double)old[c]; V = S[c] + P[c]; }
 #endif
             if (emit) sV[buf][c][tid] = V;
         }
-        j = j + 1 == B ? 0 : j + 1;
         STAMP(3);
         if (!emit) return;
         const int y = t - (B - 1);
@@ -262,7 +264,11 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
             double g[5];
 #pragma unroll
             for (int c = 0; c < 5; c++) {
-                const double *v = &sV[buf][c][tid - M_];
+                // one LDS base register per channel (kept opaque: folded into a single base the 8-bit
+                // ds_read2 offsets do not reach the other channels and every read needs its own add)
+                __attribute__((address_space(3))) const double *v =
+                    (__attribute__((address_space(3))) const double *)&sV[buf][c][tid - M_];
+                asm volatile("" : "+v"(v));
 #if OFARN_ABLATE == 2      /* one LDS read per channel instead of 15 */
                 g[c] = v[M_] * 15.0 * scale;
 #elif OFARN_ABLATE == 7    /* 15 LDS reads but no dependent add chain */
@@ -297,7 +303,21 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
         buf ^= 1;
     };
 
-    for (int step = 0; step < nsteps; step++) do_row(step, rawA, frA);
+    {
+        using K0 = std::integral_constant<int, 0>;
+        using K1 = std::integral_constant<int, 1>;
+        using K2 = std::integral_constant<int, 2>;
+        int step = 0;
+        while (step < nsteps) {
+            do_row(K0{}, step, 0, rawA, frA);
+            step++;
+            for (int jj = 1; jj < B - 1 && step < nsteps; jj++, step++) do_row(K1{}, step, jj, rawA, frA);
+            if (step < nsteps) {
+                do_row(K2{}, step, B - 1, rawA, frA);
+                step++;
+            }
+        }
+    }
 #ifdef OFARN_STAMPS
     if (up.dbg && (tid & 63) == 0)
         for (int k = 0; k < 8; k++) atomicAdd(up.dbg + k, seg[k]);
