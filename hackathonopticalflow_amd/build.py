@@ -18,8 +18,10 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libofarn.so")
 SOURCES = ["kernels_generic.hip", "kernels_fast.hip", "ofarn_api.hip"]
 HEADERS = [os.path.join(CSRC, "ofarn_internal.h"), os.path.join(CSRC, "farneback_device.h"), os.path.join(ROOT, "include", "ofarn.h")]
+# -fno-slp-vectorize: the SLP vectoriser turns pairs of f32 operations into v_pk_mul_f32 / v_pk_add_f32,
+# which measured SLOWER than two scalar VALU ops in these VALU-bound kernels (polyexp 2.42 -> 2.00 ms).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-Wall", "-Wno-unused-result"]
+         "-fno-slp-vectorize", "-Wall", "-Wno-unused-result"]
 
 
 def _stale(target, deps):
@@ -62,4 +64,4 @@ if __name__ == "__main__":
         i = args.index("--out")
         out = args[i + 1]
         del args[i:i + 2]
-    print(build(force="--force" in args, verbose=True, extra_flags=[a for a in args if a.startswith("-D")], out=out))
+    print(build(force="--force" in args, verbose=True, extra_flags=[a for a in args if a.startswith("-") and a != "--force"], out=out))
