@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512, help="frame pairs per GPU per step (config 3: 512)")
-    ap.add_argument("--wave", type=int, default=64, help="pairs resident per wave (ofarn max_batch)")
+    ap.add_argument("--wave", type=int, default=256, help="pairs resident per wave (ofarn max_batch); 256 pairs = 53 GB of workspace")
     ap.add_argument("--unique", type=int, default=32, help="distinct synthetic pairs generated, then tiled")
     ap.add_argument("--cpu-sample", type=int, default=16, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel hipEvent timing")
@@ -206,11 +206,16 @@ def main():
         per_launch_s = dom["ms"] / dom["launches"] / 1e3
         bytes_launch = STAGE_BYTES.get(dom["stage"], 0.0) * dom["units"] / dom["launches"]
         ach = bytes_launch / per_launch_s / 1e9
+        # HBM bytes from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as
+        # MI355X_MICROARCH.md prescribes; provenance inside profiles/pmc_traffic.json), measured per work unit at
+        # level 0 and scaled to this run's units per launch.
         traffic = None
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tj):
+        if os.path.exists(tj) and dom["level"] == 0:
             try:
-                traffic = json.load(open(tj)).get(dom["stage"], {}).get("hbm_bytes_per_launch")
+                per_unit = json.load(open(tj)).get(dom["stage"], {}).get("hbm_bytes_per_unit")
+                if per_unit:
+                    traffic = per_unit * dom["units"] / dom["launches"]
             except Exception:
                 traffic = None
         total_ms = sum(r["ms"] for r in prof)
