@@ -155,6 +155,37 @@ def test_pipeline_1080p_L5_config2(H, oracle):
     assert gt.mean() < 0.1
 
 
+def test_pipeline_4k_L6_I5_config5(H, oracle):
+    """BASELINE config 5 shape: 3840x2160, levels=6 (7 scales, top 60x34, 159-tap level blur), iterations=5."""
+    prev, nxt, (tx, ty) = translated_pair(2160, 3840, 5001)
+    got = H.calculate_optical_flow(prev, nxt, levels=6, iterations=5)
+    ref = oracle.farneback(prev, nxt, levels=6, iterations=5, box_mode=oracle.BOX_BLOCKED)
+    np.testing.assert_array_equal(got, ref)
+    gt = epe(got[64:-64, 64:-64], np.float32([tx, ty])[None, None])
+    assert gt.mean() < 0.1
+
+
+def test_full_size_properties_config3(H):
+    """Size-independent properties at BASELINE's full size (batch of 1080p pairs, levels=5):
+    a pair and its duplicate in the same batch give identical flow and danger maps; the interior flow
+    of every pair is its ground-truth translation; the wave split does not change results."""
+    frames, shifts = translated_pairs(3, 1080, 1920, 3000)
+    batch = np.concatenate([frames, frames[:2], frames[2:4]])   # 5 pairs: 0 1 2 0 1
+    with H.FarnebackEngine(1920, 1080, 2, levels=5) as eng:
+        flow, mask, v = eng.calc_batch(batch, H.PAIRS_INDEPENDENT)
+    np.testing.assert_array_equal(flow[0], flow[3])
+    np.testing.assert_array_equal(mask[0], mask[3])
+    np.testing.assert_array_equal(v[0], v[3])
+    np.testing.assert_array_equal(flow[1], flow[4])
+    for i in range(3):
+        gt = epe(flow[i][32:-32, 32:-32], shifts[i].astype(np.float32)[None, None])
+        assert gt.mean() < 0.1, (i, shifts[i], gt.mean())
+    with H.FarnebackEngine(1920, 1080, 5, levels=5) as eng:
+        flow2, mask2, _ = eng.calc_batch(batch, H.PAIRS_INDEPENDENT)
+    np.testing.assert_array_equal(flow, flow2)
+    np.testing.assert_array_equal(mask, mask2)
+
+
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_golden_fixtures(H, path):
     g = np.load(path, allow_pickle=False)
