@@ -501,11 +501,26 @@ __global__ __launch_bounds__(256) void k_level_hpass_multi(const uint8_t *__rest
             const int p = sx - r + rmax;             // extended index of tap 0 of the left column
             float acc0, acc1;
             if (sx + 1 < W) {
-                // right column = left column + 1: its tap t reads what the left column's tap t+1 reads
+                // right column = left column + 1: its tap t reads what the left column's tap t+1 reads.
+                // Taps go in batches of 8 so that the 16 LDS reads of a batch are in flight together
+                // (one wait per batch instead of one LDS round trip per tap).
                 float v0 = srow[skew(p)], v1 = srow[skew(p + 1)];
                 acc0 = kk[0] * v0;
                 acc1 = kk[0] * v1;
-                for (int t = 1; t < lv.ksize; t++) {
+                int t = 1;
+                for (; t + 8 <= lv.ksize; t += 8) {
+                    float vv[8], ff[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { vv[u] = srow[skew(p + t + 1 + u)]; ff[u] = kk[t + u]; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        v0 = v1;
+                        v1 = vv[u];
+                        acc0 = acc0 + ff[u] * v0;
+                        acc1 = acc1 + ff[u] * v1;
+                    }
+                }
+                for (; t < lv.ksize; t++) {
                     v0 = v1;
                     v1 = srow[skew(p + t + 1)];
                     const float f = kk[t];
