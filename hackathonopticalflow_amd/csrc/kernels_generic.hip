@@ -284,8 +284,9 @@ __global__ __launch_bounds__(256) void k_blur_solve(const float *__restrict__ M,
 __device__ __forceinline__ int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 __global__ __launch_bounds__(1024) void k_grid_filter(const float2 *__restrict__ flow, int w, int h,
-                                                       const int2 *__restrict__ pts, int P, int P2,
-                                                       uint8_t *__restrict__ mask, uint8_t *__restrict__ v)
+                                                       const int2 *__restrict__ pts, int P, int P2, int variant,
+                                                       uint8_t *__restrict__ mask, uint8_t *__restrict__ v,
+                                                       int *__restrict__ iflow)
 {
     extern __shared__ float smem[];
     float *srt = smem;          // [P2]
@@ -347,17 +348,25 @@ __global__ __launch_bounds__(1024) void k_grid_filter(const float2 *__restrict__
         const float ddx = hw - x, ddy = hh - y;
         const float mm = __fsqrt_rn(ddx * ddx + ddy * ddy);
         const float mod = __fdiv_rn(mod0, 5.0f + __fsqrt_rn(mm)) * 30.0f;
-        const bool keep = (med < mod) && (mod < p99);
+        // variant 0: pathfinder_viewer.py:173  (median*1.0 < mod) & (mod < P99)
+        // variant 1: DenseOF.py:228            mod > median*1.2   (float32 product)
+        const bool keep = variant == 1 ? (mod > med * 1.2f) : ((med < mod) && (mod < p99));
         uint8_t val = 0;
-        if (keep) {
+        if (keep || iflow) {
             const float ang = atan2f(d.y, d.x);
             const float gx = mod * cosf(ang), gy = mod * sinf(ang);
             const int nx = (int)((x + gx) + 0.5f), ny = (int)((y + gy) + 0.5f);
             const int px = (int)(x + 0.5f), py = (int)(y + 0.5f);
             const int a = nx - px, b = ny - py;
+            if (iflow) {
+                iflow[((size_t)blockIdx.x * P + i) * 2] = a;
+                iflow[((size_t)blockIdx.x * P + i) * 2 + 1] = b;
+            }
+          if (keep) {
             double vv = 50.0 + sqrt((double)(a * a + b * b)) * 2.0;
             if (vv > 255.0) vv = 255.0;
             val = (uint8_t)vv;
+          }
         }
         mask[(size_t)blockIdx.x * P + i] = keep ? 1 : 0;
         v[(size_t)blockIdx.x * P + i] = val;
@@ -438,13 +447,13 @@ int grid_filter_lds_bytes(int P)
 }
 
 void launch_grid_filter(hipStream_t s, const float *flow, int w, int h, int npairs, const int *d_pts, int P,
-                        uint8_t *mask, uint8_t *v)
+                        int variant, uint8_t *mask, uint8_t *v, int32_t *iflow)
 {
     int p2 = 1;
     while (p2 < P) p2 <<= 1;
     hipLaunchKernelGGL(k_grid_filter, dim3(npairs), dim3(1024), (size_t)p2 * sizeof(float), s,
                        reinterpret_cast<const float2 *>(flow), w, h, reinterpret_cast<const int2 *>(d_pts), P,
-                       p2, mask, v);
+                       p2, variant, mask, v, iflow);
 }
 
 }  // namespace ofarn

@@ -202,6 +202,8 @@ int check_params(const ofarn_params *p)
     if (p->flags != 0)
         return fail(OFARN_E_UNSUPPORTED, "flags=%d: OPTFLOW_USE_INITIAL_FLOW / OPTFLOW_FARNEBACK_GAUSSIAN are not built yet", p->flags);
     if (p->grid_step < 1) return fail(OFARN_E_INVALID, "grid_step must be >= 1, got %d", p->grid_step);
+    if (p->filter_variant != 0 && p->filter_variant != 1)
+        return fail(OFARN_E_INVALID, "filter_variant must be 0 or 1, got %d", p->filter_variant);
     return OFARN_OK;
 }
 
@@ -436,7 +438,7 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
     if ((d_mask || d_v) && c->P > 0) {
         if (!d_mask || !d_v) return fail(OFARN_E_INVALID, "danger mask and v must be given together");
         timed(c, s, OFARN_STAGE_GRID_FILTER, 0, (double)c->P * npairs, [&] {
-            launch_grid_filter(s, prev, w, h, npairs, c->d_pts, c->P, d_mask, d_v);
+            launch_grid_filter(s, prev, w, h, npairs, c->d_pts, c->P, c->prm.filter_variant, d_mask, d_v, nullptr);
         });
     }
     HIP_TRY(hipGetLastError());
@@ -485,7 +487,7 @@ void ofarn_default_params(ofarn_params *p)
 {
     if (!p) return;
     p->pyr_scale = 0.5; p->levels = 3; p->winsize = 15; p->iterations = 3;
-    p->poly_n = 5; p->poly_sigma = 1.2; p->flags = 0; p->grid_step = 30;
+    p->poly_n = 5; p->poly_sigma = 1.2; p->flags = 0; p->grid_step = 30; p->filter_variant = 0;
 }
 
 const char *ofarn_last_error(void) { return g_err.c_str(); }
@@ -729,7 +731,7 @@ int ofarn_calc(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next, int w
 }
 
 int ofarn_grid_filter_device(ofarn_ctx *c, const float *d_flow, int n, int w, int h, uint8_t *d_mask, uint8_t *d_v,
-                             void *hip_stream)
+                             int32_t *d_iflow, void *hip_stream)
 {
     int rc = check_size(c, w, h);
     if (rc) return rc;
@@ -740,12 +742,13 @@ int ofarn_grid_filter_device(ofarn_ctx *c, const float *d_flow, int n, int w, in
     if ((rc = make_plan(c, w, h))) return rc;
     if (c->P == 0) return OFARN_OK;
     hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
-    launch_grid_filter(s, d_flow, w, h, n, c->d_pts, c->P, d_mask, d_v);
+    launch_grid_filter(s, d_flow, w, h, n, c->d_pts, c->P, c->prm.filter_variant, d_mask, d_v, d_iflow);
     HIP_TRY(hipGetLastError());
     return OFARN_OK;
 }
 
-int ofarn_grid_filter(ofarn_ctx *c, const float *h_flow, int n, int w, int h, uint8_t *h_mask, uint8_t *h_v)
+int ofarn_grid_filter(ofarn_ctx *c, const float *h_flow, int n, int w, int h, uint8_t *h_mask, uint8_t *h_v,
+                      int32_t *h_iflow)
 {
     int rc = check_size(c, w, h);
     if (rc) return rc;
@@ -757,13 +760,19 @@ int ofarn_grid_filter(ofarn_ctx *c, const float *h_flow, int n, int w, int h, ui
     if (c->P == 0) return OFARN_OK;
     const size_t fsz = (size_t)w * h * 2 * sizeof(float);
     if ((rc = ensure_staging(c, 0, fsz, (size_t)c->P))) return rc;
+    int32_t *d_if = nullptr;
+    if (h_iflow) HIP_TRY(hipMalloc((void **)&d_if, (size_t)c->P * 2 * sizeof(int32_t)));
     for (int i = 0; i < n; i++) {
         HIP_TRY(hipMemcpyAsync(c->st_flow, h_flow + (size_t)i * w * h * 2, fsz, hipMemcpyHostToDevice, c->stream));
-        launch_grid_filter(c->stream, c->st_flow, w, h, 1, c->d_pts, c->P, c->st_mask, c->st_v);
+        launch_grid_filter(c->stream, c->st_flow, w, h, 1, c->d_pts, c->P, c->prm.filter_variant, c->st_mask, c->st_v, d_if);
         HIP_TRY(hipMemcpyAsync(h_mask + (size_t)i * c->P, c->st_mask, c->P, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(h_v + (size_t)i * c->P, c->st_v, c->P, hipMemcpyDeviceToHost, c->stream));
+        if (h_iflow)
+            HIP_TRY(hipMemcpyAsync(h_iflow + (size_t)i * c->P * 2, d_if, (size_t)c->P * 2 * sizeof(int32_t),
+                                   hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    if (d_if) (void)hipFree(d_if);
     return OFARN_OK;
 }
 

@@ -85,6 +85,6 @@ void launch_level_hpass_multi(hipStream_t s, const uint8_t *frames, size_t frame
 // Stage F: grid sample + vector filter + danger brightness.  d_pts int2[P] grid coordinates.
 int grid_filter_lds_bytes(int P);
 void launch_grid_filter(hipStream_t s, const float *flow, int w, int h, int npairs, const int *d_pts,
-                        int P, uint8_t *mask, uint8_t *v);
+                        int P, int variant, uint8_t *mask, uint8_t *v, int32_t *iflow);
 
 }  // namespace ofarn

@@ -40,7 +40,7 @@ class OfarnParams(C.Structure):
     """struct ofarn_params (include/ofarn.h): DenseOF.py:127-128 keywords + pathfinder_viewer.py:16 step."""
     _fields_ = [("pyr_scale", C.c_double), ("levels", C.c_int), ("winsize", C.c_int),
                 ("iterations", C.c_int), ("poly_n", C.c_int), ("poly_sigma", C.c_double),
-                ("flags", C.c_int), ("grid_step", C.c_int)]
+                ("flags", C.c_int), ("grid_step", C.c_int), ("filter_variant", C.c_int)]
 
 
 _lib = None
@@ -62,9 +62,9 @@ ABI = {
     "ofarn_calc_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ofarn_grid_points": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp]),
-    "ofarn_grid_filter": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, _u8p, _u8p]),
+    "ofarn_grid_filter": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, _u8p, _u8p, C.POINTER(C.c_int32)]),
     "ofarn_grid_filter_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                           C.c_void_p, C.c_void_p]),
+                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "ofarn_level_plan": (C.c_int, [C.POINTER(OfarnParams), C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _dp]),
     "ofarn_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "ofarn_profile_read": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _dp, _dp]),
@@ -137,10 +137,14 @@ def _check(rc: int):
         _raise(rc)
 
 
+FILTER_VIEWER = 0    # pathfinder_viewer.py:173  (median < modulus) & (modulus < P99)
+FILTER_DENSEOF = 1   # DenseOF.py:228            modulus > median * 1.2
+
+
 def make_params(pyr_scale=0.5, levels=3, winsize=15, iterations=3, poly_n=5, poly_sigma=1.2, flags=0,
-                grid_step=30) -> OfarnParams:
+                grid_step=30, filter_variant=0) -> OfarnParams:
     return OfarnParams(float(pyr_scale), int(levels), int(winsize), int(iterations), int(poly_n),
-                       float(poly_sigma), int(flags), int(grid_step))
+                       float(poly_sigma), int(flags), int(grid_step), int(filter_variant))
 
 
 def level_plan(width, height, **kw):
@@ -254,8 +258,11 @@ class FarnebackEngine:
             v.ctypes.data_as(_u8p) if want_danger else None))
         return flow, mask, v
 
-    def danger_map(self, flow):
-        """Grid vector filter + V on existing dense flow float32[n,H,W,2] (or [H,W,2])."""
+    def danger_map(self, flow, return_flow=False):
+        """Grid vector filter + V on existing dense flow float32[n,H,W,2] (or [H,W,2]).
+
+        return_flow=True also returns int32[n,P,2]: `next_pts - points_` of pathfinder_viewer.py:169-178
+        for every grid point (the reference keeps the rows where mask is set)."""
         flow = np.ascontiguousarray(flow, np.float32)
         single = flow.ndim == 3
         if single:
@@ -266,8 +273,12 @@ class FarnebackEngine:
         P = len(grid_points(w, h, self.params.grid_step))
         mask = np.zeros((n, P), np.uint8)
         v = np.zeros((n, P), np.uint8)
+        iflow = np.zeros((n, P, 2), np.int32) if return_flow else None
         _check(self._lib.ofarn_grid_filter(self._h, flow.ctypes.data_as(_fp), n, w, h,
-                                           mask.ctypes.data_as(_u8p), v.ctypes.data_as(_u8p)))
+                                           mask.ctypes.data_as(_u8p), v.ctypes.data_as(_u8p),
+                                           iflow.ctypes.data_as(C.POINTER(C.c_int32)) if return_flow else None))
+        if return_flow:
+            return (mask[0], v[0], iflow[0]) if single else (mask, v, iflow)
         return (mask[0], v[0]) if single else (mask, v)
 
     # ------------------------------------------------------------------ device-memory entry points
@@ -280,9 +291,9 @@ class FarnebackEngine:
                                                  _ptr(d_flow), _ptr(d_mask), _ptr(d_v),
                                                  C.c_void_p(stream) if stream else None))
 
-    def danger_map_device(self, d_flow, n, width, height, d_mask, d_v, stream=None):
+    def danger_map_device(self, d_flow, n, width, height, d_mask, d_v, d_iflow=None, stream=None):
         _check(self._lib.ofarn_grid_filter_device(self._h, _ptr(d_flow), n, width, height, _ptr(d_mask),
-                                                  _ptr(d_v), C.c_void_p(stream) if stream else None))
+                                                  _ptr(d_v), _ptr(d_iflow), C.c_void_p(stream) if stream else None))
 
     # ------------------------------------------------------------------ per-kernel timing
     STAGES = ("level_hpass", "level_vpass", "polyexp", "flow_upsample", "update_matrices", "blur_solve",
@@ -397,12 +408,13 @@ def calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, itera
                                   poly_sigma, flags)
 
 
-def danger_map(flow, step=30, device=0):
-    """Dense adaptation of pathfinder_viewer.py:159-176 + 204-217: (mask u8[P], v u8[P]) for one flow field."""
+def danger_map(flow, step=30, device=0, filter_variant=FILTER_VIEWER, return_flow=False):
+    """Dense adaptation of pathfinder_viewer.py:159-176 + 204-217: (mask u8[P], v u8[P]) for one flow field.
+    filter_variant=FILTER_DENSEOF selects the older gate of DenseOF.py:228."""
     flow = np.asarray(flow)
     h, w = flow.shape[-3], flow.shape[-2]
-    eng = _engine_for(h, w, device, grid_step=int(step))
-    return eng.danger_map(flow)
+    eng = _engine_for(h, w, device, grid_step=int(step), filter_variant=int(filter_variant))
+    return eng.danger_map(flow, return_flow=return_flow)
 
 
 def close_cached_engines():

@@ -52,6 +52,8 @@ typedef struct ofarn_params {
     double poly_sigma;  /*                                            default 1.2 */
     int flags;          /* must be 0                                  default 0   */
     int grid_step;      /* danger-map grid step in pixels             default 30  */
+    int filter_variant; /* 0: pathfinder_viewer.py:173  median < mod < P99   default 0   */
+                        /* 1: DenseOF.py:228            mod > median * 1.2               */
 } ofarn_params;
 
 typedef struct ofarn_ctx ofarn_ctx;
@@ -93,11 +95,13 @@ int ofarn_calc_batch_device(ofarn_ctx *ctx, const uint8_t *d_frames, int n_frame
 int ofarn_grid_points(int w, int h, int step, float *h_pts);
 
 /* Vector filter + danger brightness on existing dense flow (pathfinder_viewer.py:159-176, 204-217).
- * flow: float32[n][h][w][2]; mask, v: uint8[n][P]; v is 0 where mask is 0. */
+ * flow: float32[n][h][w][2]; mask, v: uint8[n][P]; v is 0 where mask is 0.  iflow (may be NULL):
+ * int32[n][P][2], the integer vectors `next_pts - points_` of pathfinder_viewer.py:169-171,178 for
+ * EVERY grid point (the reference keeps the rows where mask is set). */
 int ofarn_grid_filter(ofarn_ctx *ctx, const float *h_flow, int n, int w, int h, uint8_t *h_mask,
-                      uint8_t *h_v);
+                      uint8_t *h_v, int32_t *h_iflow);
 int ofarn_grid_filter_device(ofarn_ctx *ctx, const float *d_flow, int n, int w, int h,
-                             uint8_t *d_mask, uint8_t *d_v, void *hip_stream);
+                             uint8_t *d_mask, uint8_t *d_v, int32_t *d_iflow, void *hip_stream);
 
 /* Level plan for a frame size: writes up to cap entries of (w, h, ksize) and sigma per level,
  * level 0 first; returns the number of scales (levels+1 after cropping).  optflowgf.cpp calc(). */

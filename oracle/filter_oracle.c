@@ -85,8 +85,9 @@ static float ofo_percentile_f32(const float *sorted, int P, float q)
  * Outputs (each may be NULL): mask u8[P]; modulus float32[P] (equalised);
  * iflow int32[P][2] = next_pts - points for EVERY point (callers apply the mask);
  * v u8[P] = danger brightness for kept points, 0 elsewhere; thr[2] = {median, p99}. */
-OFO_API int ofo_vector_filter(const float *vec, const float *pts, int P, int width, int height,
-                              uint8_t *mask, float *modulus_out, int32_t *iflow, uint8_t *v, double *thr)
+/* variant 0: pathfinder_viewer.py:173 (median*1.0 < mod) & (mod < P99);  1: DenseOF.py:228 mod > median*1.2 */
+OFO_API int ofo_vector_filter2(const float *vec, const float *pts, int P, int width, int height, int variant,
+                               uint8_t *mask, float *modulus_out, int32_t *iflow, uint8_t *v, double *thr)
 {
     if (P <= 0) return 0;
     const int half_width = (int)(width / 2.0), half_height = (int)(height / 2.0);
@@ -114,7 +115,7 @@ OFO_API int ofo_vector_filter(const float *vec, const float *pts, int P, int wid
     float p99 = ofo_percentile_f32(srt, P, 99.0f);
     if (thr) { thr[0] = med; thr[1] = p99; }
     for (int i = 0; i < P; i++) {
-        int keep = (med < mod[i]) && (mod[i] < p99);
+        int keep = variant == 1 ? (mod[i] > med * 1.2f) : ((med < mod[i]) && (mod[i] < p99));
         if (mask) mask[i] = (uint8_t)keep;
         if (v) {
             uint8_t val = 0;
@@ -130,4 +131,10 @@ OFO_API int ofo_vector_filter(const float *vec, const float *pts, int P, int wid
     if (modulus_out) memcpy(modulus_out, mod, sizeof(float) * (size_t)P);
     free(srt); free(mod);
     return 0;
+}
+
+OFO_API int ofo_vector_filter(const float *vec, const float *pts, int P, int width, int height,
+                              uint8_t *mask, float *modulus_out, int32_t *iflow, uint8_t *v, double *thr)
+{
+    return ofo_vector_filter2(vec, pts, P, width, height, 0, mask, modulus_out, iflow, v, thr);
 }

@@ -92,6 +92,9 @@ def lib(omp: bool = False) -> C.CDLL:
         l.ofo_vector_filter.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, u8p, fp,
                                         C.POINTER(C.c_int32), u8p, dp]
         l.ofo_vector_filter.restype = C.c_int
+        l.ofo_vector_filter2.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, u8p, fp,
+                                         C.POINTER(C.c_int32), u8p, dp]
+        l.ofo_vector_filter2.restype = C.c_int
         _libs[omp] = l
     return _libs[omp]
 
@@ -257,7 +260,7 @@ def grid_points_c(width, height, step=30):
     return pts
 
 
-def vector_filter_c(vec, pts, width, height):
+def vector_filter_c(vec, pts, width, height, variant=0):
     vec = np.ascontiguousarray(vec, np.float32)
     pts = np.ascontiguousarray(pts, np.float32)
     P = len(pts)
@@ -266,7 +269,7 @@ def vector_filter_c(vec, pts, width, height):
     iflow = np.empty((P, 2), np.int32)
     v = np.empty(P, np.uint8)
     thr = np.empty(2, np.float64)
-    lib().ofo_vector_filter(_fp(vec), _fp(pts), P, width, height, _u8p(mask), _fp(mod),
+    lib().ofo_vector_filter2(_fp(vec), _fp(pts), P, width, height, variant, _u8p(mask), _fp(mod),
                             iflow.ctypes.data_as(C.POINTER(C.c_int32)), _u8p(v),
                             thr.ctypes.data_as(C.POINTER(C.c_double)))
     return mask.astype(bool), mod, iflow, v, thr
@@ -290,8 +293,9 @@ def grid_points_numpy(width, height, step=30):
     return np.array(points).astype(np.float32).reshape(-1, 2)
 
 
-def vector_filter_numpy(flow_, points_, width, height):
+def vector_filter_numpy(flow_, points_, width, height, variant=0):
     """pathfinder_viewer.py:159-176, re-typed (flow_ = next_pts - points_ is the input here).
+    variant=1 uses the older gate of DenseOF.py:228 instead of pathfinder_viewer.py:173.
 
     Returns mask bool[P], modulus float32[P], int flow int32[P,2] for ALL points
     (reference keeps [mask]), int points int32[P,2]."""
@@ -308,7 +312,10 @@ def vector_filter_numpy(flow_, points_, width, height):
     next_pts = np.vstack([x + fx, y + fy]).T
     next_pts = np.int32(next_pts + 0.5)
     ipoints = np.int32(points_ + 0.5)
-    mask = (np.median(modulus) * 1.0 < modulus) & (modulus < np.percentile(modulus, 99))
+    if variant == 1:
+        mask = np.greater(modulus, np.median(modulus) * 1.2)                                   # DenseOF.py:228
+    else:
+        mask = (np.median(modulus) * 1.0 < modulus) & (modulus < np.percentile(modulus, 99))   # pathfinder_viewer.py:173
     return mask, modulus, next_pts - ipoints, ipoints
 
 
@@ -322,7 +329,7 @@ def lamp_values_numpy(iflow_kept):
     return out
 
 
-def danger_map_numpy(flow_hw2, width, height, step=30):
+def danger_map_numpy(flow_hw2, width, height, step=30, variant=0, return_flow=False):
     """Dense adaptation: sample flow[y,x] at the grid (DenseOF.py:44-45), then filter.
 
     Returns (mask u8[P], v u8[P]) with v = 0 at rejected points."""
@@ -330,8 +337,10 @@ def danger_map_numpy(flow_hw2, width, height, step=30):
     xi = pts[:, 0].astype(np.int64)
     yi = pts[:, 1].astype(np.int64)
     vec = np.ascontiguousarray(flow_hw2[yi, xi, :], np.float32)
-    mask, _, iflow, _ = vector_filter_numpy(vec, pts, width, height)
+    mask, _, iflow, _ = vector_filter_numpy(vec, pts, width, height, variant)
     v = np.zeros(len(pts), np.uint8)
     if mask.any():
         v[mask] = lamp_values_numpy(iflow[mask])
+    if return_flow:
+        return mask.astype(np.uint8), v, iflow
     return mask.astype(np.uint8), v

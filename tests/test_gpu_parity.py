@@ -269,6 +269,20 @@ def test_danger_map_mask_bit_exact_random_flow(H, oracle, w, h, step):
     assert nbad <= 0.002 * mask.size + 1
 
 
+def test_danger_map_variants_and_integer_flow(H, oracle):
+    rng = np.random.default_rng(9)
+    w, h = 640, 480
+    flow = (rng.standard_normal((h, w, 2)) * 3).astype(np.float32)
+    for variant in (H.FILTER_VIEWER, H.FILTER_DENSEOF):
+        mask, v, iflow = H.danger_map(flow, 30, filter_variant=variant, return_flow=True)
+        m_ref, v_ref, if_ref = oracle.danger_map_numpy(flow, w, h, 30, variant=variant, return_flow=True)
+        np.testing.assert_array_equal(mask, m_ref)
+        assert iflow.shape == (len(m_ref), 2) and iflow.dtype == np.int32
+        # integer vectors pass through atan2f/cosf/sinf + truncation: library-specific last ulp
+        assert (iflow != if_ref).any(axis=1).sum() <= 1
+        assert (v != v_ref).sum() <= 1
+
+
 def test_device_resident_batch_torch(H, oracle):
     torch = pytest.importorskip("torch")
     assert torch.cuda.is_available()

@@ -49,6 +49,20 @@ def test_vector_filter_mask_bit_exact(oracle, seed, w, h):
     assert np.all(cv[~mask] == 0)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_denseof_filter_variant_mask_bit_exact(oracle, seed):
+    """Older gate of DenseOF.py:228: modulus > median * 1.2 (float32 product), no percentile gate."""
+    rng = np.random.default_rng(100 + seed)
+    w, h = 1920, 1080
+    pts = oracle.grid_points_numpy(w, h, 30)
+    vec = (rng.standard_normal((len(pts), 2)) * [0.02, 1, 5, 40][seed]).astype(np.float32)
+    mask, mod, iflow, _ = oracle.vector_filter_numpy(vec, pts, w, h, variant=1)
+    cm, cmod, ciflow, _, _ = oracle.vector_filter_c(vec, pts, w, h, variant=1)
+    np.testing.assert_array_equal(cmod, mod)
+    np.testing.assert_array_equal(cm, mask)
+    assert mask.sum() > 0 and not np.array_equal(mask, oracle.vector_filter_numpy(vec, pts, w, h, variant=0)[0])
+
+
 def test_percentile_small_sizes(oracle):
     rng = np.random.default_rng(3)
     for P in (2, 3, 5, 16, 101, 352):
