@@ -223,7 +223,13 @@ struct ofarn_ctx {
     int P = 0;
     std::vector<void *> plan_allocs;
     // workspace
-    float *tmp = nullptr, *I = nullptr, *R = nullptr, *M = nullptr, *flowA = nullptr, *flowB = nullptr;
+    // two workspaces: waves of one batch alternate between them on two internal streams, so the tail
+    // of one wave's kernels overlaps the other wave's (the second is allocated on first use)
+    struct Workspace { float *tmp = nullptr, *I = nullptr, *R = nullptr, *M = nullptr, *flowA = nullptr, *flowB = nullptr; };
+    Workspace ws[2];
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    bool dual = true;            // OFARN_SINGLE_STREAM=1 disables the second workspace
     uint64_t ws_bytes = 0;
     size_t tmp_floats = 0;   // capacity of tmp in floats
     // host-API staging (lazy)
@@ -337,8 +343,9 @@ inline void timed(ofarn_ctx *c, hipStream_t s, int stage, int level, double unit
 
 // One wave: npairs <= max_batch pairs, frames already in HBM.
 int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, int pairs_mode, int w,
-             int h, float *d_flow, uint8_t *d_mask, uint8_t *d_v)
+             int h, float *d_flow, uint8_t *d_mask, uint8_t *d_v, int wi = 0)
 {
+    ofarn_ctx::Workspace &ws = c->ws[wi];
     const int fstep = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? 1 : 2;
     const int nframes = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? npairs + 1 : 2 * npairs;
     const size_t fsz = (size_t)w * h;
@@ -359,9 +366,9 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
             if (march0 && L.w == w && L.h == h && L.ksize == 3) continue;   // fused into the poly expansion
             const size_t need = (size_t)nframes * h * L.w * 2;
             if (HL.n >= 12 || off + need > c->tmp_floats) { ok = false; break; }
-            HL.lv[HL.n++] = HLevel{L.d_kern, L.d_xofs, c->tmp + off, L.w, L.ksize};
+            HL.lv[HL.n++] = HLevel{L.d_kern, L.d_xofs, ws.tmp + off, L.w, L.ksize};
             if (L.ksize / 2 > HL.rmax) HL.rmax = L.ksize / 2;
-            tmp_of[k] = c->tmp + off;
+            tmp_of[k] = ws.tmp + off;
             off += need;
         }
         if (ok && HL.n > 0 && hpass_multi_lds_bytes(w, HL.rmax) <= 60 * 1024) {
@@ -382,23 +389,23 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
         if (march && L.w == w && L.h == h && L.ksize == 3) {
             // scale 1: 3-tap blur fused into the polynomial expansion, frames read directly
             timed(c, s, OFARN_STAGE_POLYEXP, k, ufr, [&] {
-                launch_polyexp_march(s, d_frames, fsz, 1, c->R, L.w, L.h, nframes, c->poly, L.h_kern3);
+                launch_polyexp_march(s, d_frames, fsz, 1, ws.R, L.w, L.h, nframes, c->poly, L.h_kern3);
             });
         } else {
-            float *tmpk = tmp_of[k] ? tmp_of[k] : c->tmp;
+            float *tmpk = tmp_of[k] ? tmp_of[k] : ws.tmp;
             if (!tmp_of[k])
                 timed(c, s, OFARN_STAGE_LEVEL_H, k, ufr, [&] {
                     if (!c->force_generic && lds_ok)
-                        launch_level_hpass_lds(s, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, c->tmp);
+                        launch_level_hpass_lds(s, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, ws.tmp);
                     else
-                        launch_level_hpass(s, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, c->tmp);
+                        launch_level_hpass(s, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, ws.tmp);
                 });
             timed(c, s, OFARN_STAGE_LEVEL_V, k, ufr, [&] {
-                launch_level_vpass(s, tmpk, h, L.w, L.h, nframes, L.d_kern, L.ksize, L.d_xa, L.d_yofs, L.d_ya, c->I);
+                launch_level_vpass(s, tmpk, h, L.w, L.h, nframes, L.d_kern, L.ksize, L.d_xa, L.d_yofs, L.d_ya, ws.I);
             });
             timed(c, s, OFARN_STAGE_POLYEXP, k, ufr, [&] {
-                if (march) launch_polyexp_march(s, c->I, npx, 0, c->R, L.w, L.h, nframes, c->poly, L.h_kern3);
-                else launch_polyexp(s, c->I, c->R, L.w, L.h, nframes, c->poly);
+                if (march) launch_polyexp_march(s, ws.I, npx, 0, ws.R, L.w, L.h, nframes, c->poly, L.h_kern3);
+                else launch_polyexp(s, ws.I, ws.R, L.w, L.h, nframes, c->poly);
             });
         }
         if (fused) {
@@ -409,10 +416,10 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
             for (int i = 0; i < c->prm.iterations; i++) {
                 const float *busy = i == 0 ? prev : cur;
                 float *out = (i == c->prm.iterations - 1 && k == 0 && d_flow) ? d_flow
-                             : (busy == c->flowA ? c->flowB : c->flowA);
+                             : (busy == ws.flowA ? ws.flowB : ws.flowA);
                 const int mode = i == 0 ? (prev ? 1 : 0) : 2;
                 timed(c, s, OFARN_STAGE_FLOW_ITER, k, upx, [&] {
-                    launch_flow_iter(s, c->R, fstep, cur, out, L.w, L.h, npairs, c->prm.winsize, mode, prev, pw, ph,
+                    launch_flow_iter(s, ws.R, fstep, cur, out, L.w, L.h, npairs, c->prm.winsize, mode, prev, pw, ph,
                                      L.d_fxofs, L.d_fxa, L.d_fyofs, L.d_fya, mul);
                 });
                 cur = out;
@@ -420,18 +427,18 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
             prev = const_cast<float *>(cur); pw = L.w; ph = L.h;
             continue;
         }
-        float *flow = (k == 0 && d_flow) ? d_flow : (prev == c->flowA ? c->flowB : c->flowA);
+        float *flow = (k == 0 && d_flow) ? d_flow : (prev == ws.flowA ? ws.flowB : ws.flowA);
         if (!prev) HIP_TRY(hipMemsetAsync(flow, 0, npx * 2 * sizeof(float) * npairs, s));
         else
             timed(c, s, OFARN_STAGE_UPSAMPLE, k, upx, [&] {
                 launch_flow_upsample(s, prev, pw, ph, flow, L.w, L.h, npairs, L.d_fxofs, L.d_fxa, L.d_fyofs,
                                      L.d_fya, mul);
             });
-        timed(c, s, OFARN_STAGE_MATRICES, k, upx, [&] { launch_update_matrices(s, c->R, fstep, flow, c->M, L.w, L.h, npairs); });
+        timed(c, s, OFARN_STAGE_MATRICES, k, upx, [&] { launch_update_matrices(s, ws.R, fstep, flow, ws.M, L.w, L.h, npairs); });
         for (int i = 0; i < c->prm.iterations; i++) {
-            timed(c, s, OFARN_STAGE_BLUR_SOLVE, k, upx, [&] { launch_blur_solve(s, c->M, flow, L.w, L.h, npairs, c->prm.winsize); });
+            timed(c, s, OFARN_STAGE_BLUR_SOLVE, k, upx, [&] { launch_blur_solve(s, ws.M, flow, L.w, L.h, npairs, c->prm.winsize); });
             if (i < c->prm.iterations - 1)
-                timed(c, s, OFARN_STAGE_MATRICES, k, upx, [&] { launch_update_matrices(s, c->R, fstep, flow, c->M, L.w, L.h, npairs); });
+                timed(c, s, OFARN_STAGE_MATRICES, k, upx, [&] { launch_update_matrices(s, ws.R, fstep, flow, ws.M, L.w, L.h, npairs); });
         }
         prev = flow; pw = L.w; ph = L.h;
     }
@@ -479,6 +486,40 @@ int ensure_staging(ofarn_ctx *c, size_t frames_bytes, size_t flow_bytes, size_t 
     return OFARN_OK;
 }
 
+// Allocates workspace `wi` for max_batch pairs at max_w x max_h.  Returns 0 on success.
+int alloc_workspace(ofarn_ctx *c, int wi)
+{
+    ofarn_ctx::Workspace &ws = c->ws[wi];
+    if (ws.tmp) return 0;
+    const size_t px = (size_t)c->max_w * c->max_h;
+    const size_t F = (size_t)2 * c->max_batch, Pn = (size_t)c->max_batch;
+    struct { float **p; size_t n; } req[] = {
+        {&ws.tmp, F * px * 2}, {&ws.I, F * px}, {&ws.R, F * (px * 5 + 4)}, {&ws.M, Pn * px * 5},
+        {&ws.flowA, Pn * px * 2}, {&ws.flowB, Pn * px * 2}};
+    for (auto &r : req) {
+        const size_t bytes = r.n * sizeof(float) + 256;
+        if (hipMalloc((void **)r.p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            for (auto &q : req) if (*q.p) { (void)hipFree(*q.p); *q.p = nullptr; }
+            fail(OFARN_E_NOMEM, "workspace of %zu bytes does not fit (max_batch=%d at %dx%d)", bytes, c->max_batch, c->max_w, c->max_h);
+            return 1;
+        }
+        c->ws_bytes += bytes;
+    }
+    if (!c->aux[wi]) {
+        if (hipStreamCreateWithFlags(&c->aux[wi], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_join[wi], hipEventDisableTiming) != hipSuccess) {
+            fail(OFARN_E_HIP, "stream/event creation failed");
+            return 1;
+        }
+    }
+    if (!c->ev_fork && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) {
+        fail(OFARN_E_HIP, "event creation failed");
+        return 1;
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -523,18 +564,13 @@ int ofarn_create(const ofarn_params *params, int device, int max_w, int max_h, i
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
         return bail(fail(OFARN_E_HIP, "stream/event creation failed"));
-    const size_t px = (size_t)max_w * max_h;
-    const size_t F = (size_t)2 * max_batch, Pn = (size_t)max_batch;
-    struct { float **p; size_t n; } req[] = {
-        {&c->tmp, F * px * 2}, {&c->I, F * px}, {&c->R, F * (px * 5 + 4)}, {&c->M, Pn * px * 5},
-        {&c->flowA, Pn * px * 2}, {&c->flowB, Pn * px * 2}};
-    c->tmp_floats = F * px * 2;
-    for (auto &r : req) {
-        const size_t bytes = r.n * sizeof(float) + 256;
-        if (hipMalloc((void **)r.p, bytes) != hipSuccess)
-            return bail(fail(OFARN_E_NOMEM, "workspace of %zu bytes does not fit (max_batch=%d at %dx%d)", bytes, max_batch, max_w, max_h));
-        c->ws_bytes += bytes;
+    {
+        const char *e = getenv("OFARN_SINGLE_STREAM");
+        c->dual = !(e && e[0] == '1');
     }
+    const size_t px = (size_t)max_w * max_h;
+    c->tmp_floats = (size_t)2 * max_batch * px * 2;
+    if (alloc_workspace(c, 0)) return bail(OFARN_E_NOMEM);
     *out = c;
     return OFARN_OK;
 }
@@ -545,7 +581,14 @@ void ofarn_destroy(ofarn_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_plan(c);
-    for (float *p : {c->tmp, c->I, c->R, c->M, c->flowA, c->flowB, c->st_flow}) if (p) (void)hipFree(p);
+    for (auto &ws : c->ws)
+        for (float *p : {ws.tmp, ws.I, ws.R, ws.M, ws.flowA, ws.flowB}) if (p) (void)hipFree(p);
+    if (c->st_flow) (void)hipFree(c->st_flow);
+    for (int i = 0; i < 2; i++) {
+        if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (uint8_t *p : {c->st_frames, c->st_mask, c->st_v}) if (p) (void)hipFree(p);
     for (auto &r : c->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : c->prof_free) (void)hipEventDestroy(e);
@@ -648,13 +691,29 @@ int ofarn_calc_batch_device(ofarn_ctx *c, const uint8_t *d_frames, int n_frames,
     hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
     const size_t fsz = (size_t)w * h;
     const int fstep = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? 1 : 2;
-    for (int p0 = 0; p0 < n_pairs; p0 += c->max_batch) {
+    const int nwaves = (n_pairs + c->max_batch - 1) / c->max_batch;
+    // More than one wave: alternate them over two internal streams (each with its own workspace), forked
+    // from and joined back into the caller's stream with events.  Per-kernel profiling keeps one stream.
+    const bool dual = c->dual && nwaves > 1 && !c->prof_on && alloc_workspace(c, 1) == 0;
+    if (dual) {
+        HIP_TRY(hipEventRecord(c->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
+        HIP_TRY(hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
+    }
+    int wi = 0;
+    for (int p0 = 0; p0 < n_pairs; p0 += c->max_batch, wi ^= 1) {
         const int np = n_pairs - p0 < c->max_batch ? n_pairs - p0 : c->max_batch;
-        rc = run_wave(c, s, d_frames + (size_t)p0 * fstep * fsz, np, pairs_mode, w, h,
+        rc = run_wave(c, dual ? c->aux[wi] : s, d_frames + (size_t)p0 * fstep * fsz, np, pairs_mode, w, h,
                       d_flow ? d_flow + (size_t)p0 * fsz * 2 : nullptr,
-                      d_mask ? d_mask + (size_t)p0 * c->P : nullptr, d_v ? d_v + (size_t)p0 * c->P : nullptr);
+                      d_mask ? d_mask + (size_t)p0 * c->P : nullptr, d_v ? d_v + (size_t)p0 * c->P : nullptr,
+                      dual ? wi : 0);
         if (rc) return rc;
     }
+    if (dual)
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(hipEventRecord(c->ev_join[i], c->aux[i]));
+            HIP_TRY(hipStreamWaitEvent(s, c->ev_join[i], 0));
+        }
     return OFARN_OK;
 }
 
@@ -793,11 +852,11 @@ int ofarn_stage_level_image(ofarn_ctx *c, const uint8_t *h_img, int w, int h, in
     HIP_TRY(hipMemcpyAsync(c->st_frames, h_img, fsz, hipMemcpyHostToDevice, c->stream));
     const bool lds_ok = (size_t)(w + 2 * (L.ksize / 2)) * 4 * 33 / 32 + 4 * (size_t)L.ksize + 64 <= 60 * 1024;
     if (!c->force_generic && lds_ok)
-        launch_level_hpass_lds(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->tmp);
+        launch_level_hpass_lds(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->ws[0].tmp);
     else
-        launch_level_hpass(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->tmp);
-    launch_level_vpass(c->stream, c->tmp, h, L.w, L.h, 1, L.d_kern, L.ksize, L.d_xa, L.d_yofs, L.d_ya, c->I);
-    HIP_TRY(hipMemcpyAsync(h_out, c->I, (size_t)L.w * L.h * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        launch_level_hpass(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->ws[0].tmp);
+    launch_level_vpass(c->stream, c->ws[0].tmp, h, L.w, L.h, 1, L.d_kern, L.ksize, L.d_xa, L.d_yofs, L.d_ya, c->ws[0].I);
+    HIP_TRY(hipMemcpyAsync(h_out, c->ws[0].I, (size_t)L.w * L.h * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return OFARN_OK;
 }
@@ -826,14 +885,14 @@ int ofarn_stage_polyexp(ofarn_ctx *c, const float *h_img, int w, int h, float *h
     if (!h_img || !h_R) return fail(OFARN_E_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
     const size_t npx = (size_t)w * h;
-    HIP_TRY(hipMemcpyAsync(c->I, h_img, npx * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ws[0].I, h_img, npx * sizeof(float), hipMemcpyHostToDevice, c->stream));
     if (!c->force_generic && polyexp_march_supported(c->prm.poly_n)) {
         const float none[3] = {0, 0, 0};
-        launch_polyexp_march(c->stream, c->I, npx, 0, c->R, w, h, 1, c->poly, none);
+        launch_polyexp_march(c->stream, c->ws[0].I, npx, 0, c->ws[0].R, w, h, 1, c->poly, none);
     } else
-        launch_polyexp(c->stream, c->I, c->R, w, h, 1, c->poly);
+        launch_polyexp(c->stream, c->ws[0].I, c->ws[0].R, w, h, 1, c->poly);
     std::vector<float> dev(r_frame_stride(npx));
-    HIP_TRY(hipMemcpyAsync(dev.data(), c->R, dev.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(dev.data(), c->ws[0].R, dev.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     r_from_device_layout(dev, npx, h_R);
     return OFARN_OK;
@@ -850,12 +909,12 @@ int ofarn_stage_update_matrices(ofarn_ctx *c, const float *h_R0, const float *h_
     std::vector<float> d0, d1;
     r_to_device_layout(h_R0, npx, d0);
     r_to_device_layout(h_R1, npx, d1);
-    HIP_TRY(hipMemcpyAsync(c->R, d0.data(), d0.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->R + r_frame_stride(npx), d1.data(), d1.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->flowA, h_flow, npx * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    launch_update_matrices(c->stream, c->R, 1, c->flowA, c->M, w, h, 1);
+    HIP_TRY(hipMemcpyAsync(c->ws[0].R, d0.data(), d0.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ws[0].R + r_frame_stride(npx), d1.data(), d1.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ws[0].flowA, h_flow, npx * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    launch_update_matrices(c->stream, c->ws[0].R, 1, c->ws[0].flowA, c->ws[0].M, w, h, 1);
     std::vector<float> mp(npx * 5);
-    HIP_TRY(hipMemcpyAsync(mp.data(), c->M, npx * 5 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(mp.data(), c->ws[0].M, npx * 5 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (size_t o = 0; o < npx; o++)
         for (int ch = 0; ch < 5; ch++) h_M[o * 5 + ch] = mp[ch * npx + o];     // planar -> interleaved
@@ -872,9 +931,9 @@ int ofarn_stage_blur_solve(ofarn_ctx *c, const float *h_M, int w, int h, float *
     std::vector<float> mp(npx * 5);
     for (size_t o = 0; o < npx; o++)
         for (int ch = 0; ch < 5; ch++) mp[ch * npx + o] = h_M[o * 5 + ch];     // interleaved -> planar
-    HIP_TRY(hipMemcpyAsync(c->M, mp.data(), npx * 5 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    launch_blur_solve(c->stream, c->M, c->flowA, w, h, 1, c->prm.winsize);
-    HIP_TRY(hipMemcpyAsync(h_flow, c->flowA, npx * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ws[0].M, mp.data(), npx * 5 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    launch_blur_solve(c->stream, c->ws[0].M, c->ws[0].flowA, w, h, 1, c->prm.winsize);
+    HIP_TRY(hipMemcpyAsync(h_flow, c->ws[0].flowA, npx * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return OFARN_OK;
 }
@@ -900,10 +959,10 @@ int ofarn_stage_flow_upsample(ofarn_ctx *c, const float *h_flow, int sw, int sh,
     HIP_TRY(hipMemcpy(d_xa, xa.data(), dw * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_yo, yo.data(), dh * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_ya, ya.data(), dh * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpyAsync(c->flowA, h_flow, (size_t)sw * sh * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    launch_flow_upsample(c->stream, c->flowA, sw, sh, c->flowB, dw, dh, 1, d_xo, d_xa, d_yo, d_ya,
+    HIP_TRY(hipMemcpyAsync(c->ws[0].flowA, h_flow, (size_t)sw * sh * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    launch_flow_upsample(c->stream, c->ws[0].flowA, sw, sh, c->ws[0].flowB, dw, dh, 1, d_xo, d_xa, d_yo, d_ya,
                          (float)(1. / c->prm.pyr_scale));
-    HIP_TRY(hipMemcpyAsync(h_out, c->flowB, (size_t)dw * dh * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(h_out, c->ws[0].flowB, (size_t)dw * dh * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     (void)hipFree(d_xo); (void)hipFree(d_xa); (void)hipFree(d_yo); (void)hipFree(d_ya);
     return OFARN_OK;
