@@ -196,6 +196,35 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
 #endif
+    bool have_prev = false;                  // a row's column sums are in sV[buf ^ 1] awaiting their horizontal pass
+    int yprev = 0;
+    const int tc = clampi(tid, M_, FI_THREADS - M_ - 1);   // halo threads redo a neighbour's sums (no branch)
+    const bool writer = tid >= M_ && tid < FI_THREADS - M_ && x < w;
+    auto hsum_row = [&](const int b, const int y) {
+        double g[5];
+        double chain = 0;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            // One opaque LDS base register per channel (folded into a single base, the 8-bit ds_read2
+            // offsets do not reach the other channels and every read needs its own add).  The base is
+            // also chained on the previous channel's sum: left alone the scheduler issues all 75 reads
+            // up front (150 VGPRs -> spills); chained, at most one channel's reads are in flight and
+            // the other row's independent work fills the latency.
+            __attribute__((address_space(3))) const double *v =
+                (__attribute__((address_space(3))) const double *)&sV[b][c][tc - M_];
+            asm volatile("" : "+v"(v), "+v"(chain));
+            double s2 = v[0];
+#pragma unroll
+            for (int i = 1; i < TAPS; i++) s2 += v[i];
+            g[c] = s2 * scale;
+            chain = s2;
+        }
+        const double idet = 1. / (g[0] * g[2] - g[1] * g[1] + 1e-3);
+        float2 o;
+        o.x = (float)((g[0] * g[4] - g[1] * g[3]) * idet);
+        o.y = (float)((g[2] * g[3] - g[1] * g[4]) * idet);
+        if (writer) stg_f2(fout, ((unsigned)y * (unsigned)w + (unsigned)x) * 8u, o);
+    };
     // KIND 0: first row of a block (j == 0), 1: middle rows, 2: last row (j == B-1) -- compile-time so
     // the P/S updates need no selects.
     auto do_row = [&](auto kind_c, const int step, const int j, GatherRaw &raw, FlowRaw &fr) {
@@ -242,6 +271,12 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
             for (int c = FI_REGCH; c < 5; c++) { old[c] = sF[c - FI_REGCH][ju][tid]; sF[c - FI_REGCH][ju][tid] = m[c]; }
         }
         const bool emit = step >= B - 1;           // uniform: output row y = t-(B-1) >= y0
+        // Skewed pipeline: the horizontal pass + solve of the PREVIOUS output row (its column sums were
+        // exchanged one step ago) sits in the same straight-line code as this row's column sums, so
+        // the scheduler can interleave the LDS reads and f64 add chains of one with the f32 math,
+        // register-FIFO traffic and f64 updates of the other.  One barrier per step.
+        if (have_prev) hsum_row(buf ^ 1, yprev);
+        STAMP(5);
 #pragma unroll
         for (int c = 0; c < 5; c++) {
             const double vn = (double)m[c];
@@ -257,49 +292,10 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
         }
         STAMP(3);
         if (!emit) return;
-        const int y = t - (B - 1);
         barrier_lds_only();
         STAMP(4);
-        if (tid >= M_ && tid < FI_THREADS - M_ && x < w) {
-            double g[5];
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                // one LDS base register per channel (kept opaque: folded into a single base the 8-bit
-                // ds_read2 offsets do not reach the other channels and every read needs its own add)
-                __attribute__((address_space(3))) const double *v =
-                    (__attribute__((address_space(3))) const double *)&sV[buf][c][tid - M_];
-                asm volatile("" : "+v"(v));
-#if OFARN_ABLATE == 2      /* one LDS read per channel instead of 15 */
-                g[c] = v[M_] * 15.0 * scale;
-#elif OFARN_ABLATE == 7    /* 15 LDS reads but no dependent add chain */
-                double s2 = 0;
-#pragma unroll
-                for (int i = 0; i < TAPS; i += 2) s2 += v[i];
-                g[c] = s2 * scale;
-#else
-                // LDS reads in two batches (register budget), each ahead of its adds
-                constexpr int H0 = (TAPS + 1) / 2;
-                double ta[H0], tb[TAPS - H0];
-#pragma unroll
-                for (int i = 0; i < H0; i++) ta[i] = v[i];
-                double s2 = ta[0];
-#pragma unroll
-                for (int i = 0; i < TAPS - H0; i++) tb[i] = v[H0 + i];
-#pragma unroll
-                for (int i = 1; i < H0; i++) s2 += ta[i];
-#pragma unroll
-                for (int i = 0; i < TAPS - H0; i++) s2 += tb[i];
-                g[c] = s2 * scale;
-#endif
-            }
-            STAMP(5);
-            const double idet = 1. / (g[0] * g[2] - g[1] * g[1] + 1e-3);
-            float2 o;
-            o.x = (float)((g[0] * g[4] - g[1] * g[3]) * idet);
-            o.y = (float)((g[2] * g[3] - g[1] * g[4]) * idet);
-            stg_f2(fout, ((unsigned)y * (unsigned)w + (unsigned)x) * 8u, o);
-        }
-        STAMP(6);
+        have_prev = true;
+        yprev = t - (B - 1);
         buf ^= 1;
     };
 
@@ -317,6 +313,7 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
                 step++;
             }
         }
+        if (have_prev) hsum_row(buf ^ 1, yprev);     // drain the pipeline: last output row
     }
 #ifdef OFARN_STAMPS
     if (up.dbg && (tid & 63) == 0)
