@@ -121,13 +121,8 @@ __device__ __forceinline__ void gather_issue(const float *__restrict__ R0, const
     // out-of-range taps are never used; read pixel 0 instead so the loads stay unconditional
     const unsigned q = g.inb ? (unsigned)y1 * (unsigned)w + (unsigned)x1 : 0u;
     const unsigned q01 = g.inb ? q + 1u : 0u, q10 = g.inb ? q + (unsigned)w : 0u, q11 = g.inb ? q + (unsigned)w + 1u : 0u;
-#if defined(OFARN_ABLATE) && (OFARN_ABLATE == 1 || OFARN_ABLATE == 6)
-    (void)q01; (void)q10; (void)q11;
-    for (int c = 0; c < 5; c++) { g.t00[c] = g.r0[c]; g.t01[c] = g.r0[c]; g.t10[c] = g.r0[c]; g.t11[c] = g.r0[c]; }
-#else
     load_r(R1, npx, q, g.t00); load_r(R1, npx, q01, g.t01);
     load_r(R1, npx, q10, g.t10); load_r(R1, npx, q11, g.t11);
-#endif
 }
 
 // Branch-free: a divergent branch here makes the compiler drain every outstanding load at the

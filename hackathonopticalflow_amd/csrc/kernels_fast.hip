@@ -56,12 +56,8 @@ template <> struct FifoVec<11> { typedef ofarn_f16v type; };
 template <> struct FifoVec<13> { typedef ofarn_f16v type; };
 template <> struct FifoVec<15> { typedef ofarn_f16v type; };
 
-// Timing-only ablations for profiling (never defined in the product build; results are wrong):
-//   OFARN_ABLATE 1: R1 taps not gathered (R0 reused)   2: no horizontal LDS pass   3: no f64 column sums
-//   OFARN_FI_WAVES: minimum waves per SIMD asked of the register allocator (default: none)
-#ifndef OFARN_ABLATE
-#define OFARN_ABLATE 0
-#endif
+// OFARN_FI_WAVES: minimum waves per SIMD asked of the register allocator; OFARN_FI_REGCH: channels whose
+// 15-row FIFO lives in registers (the rest in LDS).  3 / 3 gives 3 waves per SIMD and 3 blocks per CU.
 #ifndef OFARN_FI_WAVES
 #define OFARN_FI_WAVES 3
 #endif
@@ -250,19 +246,6 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
             __builtin_amdgcn_sched_barrier(0);
         }
         STAMP(2);
-#if OFARN_ABLATE == 8      /* memory pattern only: loads + trivial ALU + store of the INPUT flow */
-        {
-            float acc = 0.f;
-#pragma unroll
-            for (int c = 0; c < 5; c++) acc += m[c];
-            if (step >= B - 1 && tid >= M_ && tid < FI_THREADS - M_ && x < w) {
-                float2 o = MODE == 2 ? ldg_f2(fin, ((unsigned)(t - (B - 1)) * (unsigned)w + (unsigned)x) * 8u) : make_float2(0.f, 0.f);
-                o.x += acc * 1e-30f;
-                stg_f2(fout, ((unsigned)(t - (B - 1)) * (unsigned)w + (unsigned)x) * 8u, o);
-            }
-            return;
-        }
-#endif
         {
             const int ju = __builtin_amdgcn_readfirstlane(j);
 #pragma unroll
@@ -280,14 +263,10 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
 #pragma unroll
         for (int c = 0; c < 5; c++) {
             const double vn = (double)m[c];
-#if OFARN_ABLATE == 3
-            const double V = vn;
-#else
             double V;
             if constexpr (KIND == 0) P[c] = vn; else P[c] = P[c] + vn;
             if constexpr (KIND == 2) { V = P[c]; S[c] = P[c]; }
             else { S[c] = S[c] - (double)old[c]; V = S[c] + P[c]; }
-#endif
             if (emit) sV[buf][c][tid] = V;
         }
         STAMP(3);
@@ -537,14 +516,19 @@ __global__ __launch_bounds__(256) void k_level_hpass_multi(const uint8_t *__rest
 static inline unsigned cdivu(int a, int b) { return (unsigned)((a + b - 1) / b); }
 int best_strip_units(int nunits, int unit, int warm, int blocks_per_strip_row, int blocks_per_cu);
 
-bool flow_iter_supported(int winsize) { return winsize / 2 == 7; }
-
-// mode 0: zero input flow; 1: upsample from coarse (up_* valid); 2: read flow_in.
-void launch_flow_iter(hipStream_t s, const float *R, int fstep, const float *flow_in, float *flow_out, int w,
-                      int h, int npairs, int winsize, int mode, const float *coarse, int cw, int ch,
-                      const int *d_xofs, const float *d_xa, const int *d_yofs, const float *d_ya, float mul)
+// The fused kernel is instantiated for these window half-widths m = winsize/2 (winsize 7..21 and
+// the even sizes sharing an m); other window sizes take the generic unfused kernels.
+bool flow_iter_supported(int winsize)
 {
-    constexpr int M_ = 7;
+    const int m = winsize / 2;
+    return m == 3 || m == 5 || m == 7 || m == 10;
+}
+
+template <int M_>
+static void launch_flow_iter_m(hipStream_t s, const float *R, int fstep, const float *flow_in, float *flow_out, int w,
+                               int h, int npairs, int winsize, int mode, const float *coarse, int cw, int ch,
+                               const int *d_xofs, const float *d_xa, const int *d_yofs, const float *d_ya, float mul)
+{
     constexpr int OUTW = FI_THREADS - 2 * M_;
     constexpr int B = 2 * M_ + 1;
     // strips start on block boundaries of the blocked column sums (multiples of B rows); their
@@ -565,9 +549,9 @@ void launch_flow_iter(hipStream_t s, const float *R, int fstep, const float *flo
         (void)hipMemcpy(hbuf, dbg, 64, hipMemcpyDeviceToHost);
         double tot = 0;
         for (int k = 0; k < 8; k++) tot += (double)hbuf[k];
-        fprintf(stderr, "[stamps] wait-loads %.1f%% matrices %.1f%% issue %.1f%% colsum+ldsw %.1f%% barrier %.1f%% hsum %.1f%% solve+store %.1f%% loop-ovh %.1f%%\n",
-                100 * hbuf[0] / tot, 100 * hbuf[1] / tot, 100 * hbuf[2] / tot, 100 * hbuf[3] / tot, 100 * hbuf[4] / tot,
-                100 * hbuf[5] / tot, 100 * hbuf[6] / tot, 100 * hbuf[7] / tot);
+        fprintf(stderr, "[stamps] wait-loads %.1f%% matrices %.1f%% issue %.1f%% hsum(prev row) %.1f%% colsum+ldsw %.1f%% barrier %.1f%% loop-ovh %.1f%%\n",
+                100 * hbuf[0] / tot, 100 * hbuf[1] / tot, 100 * hbuf[2] / tot, 100 * hbuf[5] / tot, 100 * hbuf[3] / tot,
+                100 * hbuf[4] / tot, 100 * hbuf[7] / tot);
         (void)hipMemset(dbg, 0, 64);
     }
 #endif
@@ -579,6 +563,23 @@ void launch_flow_iter(hipStream_t s, const float *R, int fstep, const float *flo
         hipLaunchKernelGGL((k_flow_iter<M_, 1>), grid, dim3(FI_THREADS), 0, s, R, fstep, fin, fout, w, h, strip_h, scale, up);
     else
         hipLaunchKernelGGL((k_flow_iter<M_, 2>), grid, dim3(FI_THREADS), 0, s, R, fstep, fin, fout, w, h, strip_h, scale, up);
+}
+
+// mode 0: zero input flow; 1: upsample from coarse (up_* valid); 2: read flow_in.
+void launch_flow_iter(hipStream_t s, const float *R, int fstep, const float *flow_in, float *flow_out, int w,
+                      int h, int npairs, int winsize, int mode, const float *coarse, int cw, int ch,
+                      const int *d_xofs, const float *d_xa, const int *d_yofs, const float *d_ya, float mul)
+{
+#define OFARN_FI_CASE(M)                                                                                          \
+    case M:                                                                                                       \
+        launch_flow_iter_m<M>(s, R, fstep, flow_in, flow_out, w, h, npairs, winsize, mode, coarse, cw, ch, d_xofs, \
+                              d_xa, d_yofs, d_ya, mul);                                                            \
+        break;
+    switch (winsize / 2) {
+        OFARN_FI_CASE(3) OFARN_FI_CASE(5) OFARN_FI_CASE(7) OFARN_FI_CASE(10)
+        default: break;
+    }
+#undef OFARN_FI_CASE
 }
 
 }  // namespace ofarn

