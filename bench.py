@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=16, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel hipEvent timing")
     ap.add_argument("--prof-table", action="store_true", help="print per-(stage, level) timing rows to stderr")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (gloo: rehearsal of the multi-rank path with "
+                         "several ranks sharing one GPU; the gather then goes through host memory)")
     args = ap.parse_args()
 
     import torch
@@ -135,12 +138,13 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: hackathonopticalflow_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    dist = D.init_process_group("nccl") if world > 1 else None
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    dist = D.init_process_group(args.backend) if world > 1 else None
 
     B = args.batch
-    eng = ofa.FarnebackEngine(W, H, min(args.wave, B), local_rank, **PARAMS)
+    eng = ofa.FarnebackEngine(W, H, min(args.wave, B), dev_index, **PARAMS)
     P = len(ofa.grid_points(W, H, 30))
     plan = ofa.level_plan(W, H, **PARAMS)
 
@@ -158,6 +162,8 @@ def main():
     def step():
         eng.calc_batch_device(frames, 2 * B, W, H, ofa.PAIRS_INDEPENDENT, flow, mask, v, stream=stream)
         if dist is not None:
+            if args.backend == "gloo":
+                return D.gather_danger_maps(mask.cpu(), v.cpu(), B * world, dist)
             return D.gather_danger_maps(mask, v, B * world, dist)
         return mask, v
 
@@ -178,7 +184,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = [] if args.no_profile else eng.profile_read()
