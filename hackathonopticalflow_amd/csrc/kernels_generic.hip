@@ -275,6 +275,69 @@ __global__ __launch_bounds__(256) void k_blur_solve(const float *__restrict__ M,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stage D, OPTFLOW_FARNEBACK_GAUSSIAN.  FarnebackUpdateFlow_GaussianBlur: separable Gaussian window
+// (sigma = 0.3*m, m = winsize/2), float32 throughout, replicate borders, then the same solve.
+//   column: s0 = M[y][x]*k[0];  s0 += (M[y+i][x] + M[y-i][x]) * k[i]      (i = 1..m)
+//   row   : sum = v[x]*k[0];    sum += k[i] * (v[x-i] + v[x+i])           (i = 1..m)
+// One 64x16 tile per block, one channel at a time through LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int GS_TW = 64, GS_TH = 16;
+
+__global__ __launch_bounds__(256) void k_gauss_solve(const float *__restrict__ M, float2 *__restrict__ flow,
+                                                      int w, int h, int m, const float *__restrict__ kern)
+{
+    extern __shared__ float gsm[];
+    const int IW = GS_TW + 2 * m, IH = GS_TH + 2 * m;
+    float *sM = gsm;                 // [IH][IW]
+    float *sVf = sM + IH * IW;       // [GS_TH][IW]
+    float *sK = sVf + GS_TH * IW;    // [m+1]
+    const int x0 = blockIdx.x * GS_TW, y0 = blockIdx.y * GS_TH;
+    const size_t npx = (size_t)w * h;
+    const int tid = threadIdx.x;
+    const int ox = tid & 63, oy = tid >> 6;   // rows oy, oy+4, oy+8, oy+12
+    float acc[4][5];
+    for (int i = tid; i <= m; i += 256) sK[i] = kern[i];
+    for (int c = 0; c < 5; c++) {
+        const float *src = M + ((size_t)blockIdx.z * 5 + c) * npx;
+        for (int i = tid; i < IH * IW; i += 256) {
+            const int ly = i / IW, lx = i - ly * IW;
+            const int gx = clampi(x0 - m + lx, 0, w - 1), gy = clampi(y0 - m + ly, 0, h - 1);
+            sM[i] = src[(size_t)gy * w + gx];
+        }
+        __syncthreads();
+        for (int i = tid; i < GS_TH * IW; i += 256) {
+            const int ly = i / IW, lx = i - ly * IW;
+            const float *col = sM + (ly + m) * IW + lx;
+            float s0 = col[0] * sK[0];
+            for (int k = 1; k <= m; k++) s0 = s0 + (col[k * IW] + col[-k * IW]) * sK[k];
+            sVf[i] = s0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float *rowv = sVf + (oy + 4 * q) * IW + ox + m;
+            float sum = rowv[0] * sK[0];
+            for (int k = 1; k <= m; k++) sum = sum + sK[k] * (rowv[-k] + rowv[k]);
+            acc[q][c] = sum;
+        }
+        __syncthreads();
+    }
+    const int gx = x0 + ox;
+    if (gx >= w) return;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int gy = y0 + oy + 4 * q;
+        if (gy >= h) continue;
+        const double g11 = acc[q][0], g12 = acc[q][1], g22 = acc[q][2], h1 = acc[q][3], h2 = acc[q][4];
+        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+        float2 o;
+        o.x = (float)((g11 * h2 - g12 * h1) * idet);
+        o.y = (float)((g22 * h1 - g12 * h2) * idet);
+        flow[(size_t)blockIdx.z * npx + (size_t)gy * w + gx] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stage F.  Sample flow[y][x] at the measurement grid (DenseOF.py:44-45), the vector filter of
 // pathfinder_viewer.py:159-176 and the V value of pathfinder_viewer.py:204-217.
 // One block per pair.  The equalised moduli are bitonic-sorted in LDS to read the order
@@ -437,6 +500,22 @@ void launch_blur_solve(hipStream_t s, const float *M, float *flow, int w, int h,
     dim3 grid(cdiv(w, TW), cdiv(h, B), npairs);
     hipLaunchKernelGGL(k_blur_solve, grid, dim3(256), lds, s, M, reinterpret_cast<float2 *>(flow), w, h, m, TW,
                        scale);
+}
+
+void launch_gauss_solve(hipStream_t s, const float *M, float *flow, int w, int h, int npairs, int winsize,
+                        const float *d_kern)
+{
+    const int m = winsize / 2;
+    const int IW = GS_TW + 2 * m, IH = GS_TH + 2 * m;
+    const size_t lds = sizeof(float) * (size_t)(IH * IW + GS_TH * IW + m + 1);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gauss_solve),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    dim3 grid(cdiv(w, GS_TW), cdiv(h, GS_TH), npairs);
+    hipLaunchKernelGGL(k_gauss_solve, grid, dim3(256), lds, s, M, reinterpret_cast<float2 *>(flow), w, h, m, d_kern);
 }
 
 int grid_filter_lds_bytes(int P)

@@ -199,8 +199,10 @@ int check_params(const ofarn_params *p)
     if (p->iterations < 0) return fail(OFARN_E_INVALID, "iterations must be >= 0, got %d", p->iterations);
     if (p->poly_n < 1 || p->poly_n > kMaxPolyN)
         return fail(OFARN_E_INVALID, "poly_n must be in [1, %d], got %d", kMaxPolyN, p->poly_n);
-    if (p->flags != 0)
-        return fail(OFARN_E_UNSUPPORTED, "flags=%d: OPTFLOW_USE_INITIAL_FLOW / OPTFLOW_FARNEBACK_GAUSSIAN are not built yet", p->flags);
+    if (p->flags & ~OFARN_FLAG_FARNEBACK_GAUSSIAN)
+        return fail(OFARN_E_UNSUPPORTED, "flags=%d: only OPTFLOW_FARNEBACK_GAUSSIAN (256) is built; OPTFLOW_USE_INITIAL_FLOW (4) is not", p->flags);
+    if ((p->flags & OFARN_FLAG_FARNEBACK_GAUSSIAN) && p->winsize / 2 > 60)
+        return fail(OFARN_E_INVALID, "winsize must be <= 121 with OPTFLOW_FARNEBACK_GAUSSIAN, got %d", p->winsize);
     if (p->grid_step < 1) return fail(OFARN_E_INVALID, "grid_step must be >= 1, got %d", p->grid_step);
     if (p->filter_variant != 0 && p->filter_variant != 1)
         return fail(OFARN_E_INVALID, "filter_variant must be 0 or 1, got %d", p->filter_variant);
@@ -216,6 +218,7 @@ struct ofarn_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     PolyCoef poly{};
+    float *d_gwin = nullptr;     // m+1 taps of the OPTFLOW_FARNEBACK_GAUSSIAN window
     // plan (cached for one frame size)
     int plan_w = 0, plan_h = 0;
     std::vector<Level> lv;
@@ -352,7 +355,8 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
     const int nlev = (int)c->lv.size() - 1;
     float *prev = nullptr;
     int pw = 0, ph = 0;
-    const bool fused = !c->force_generic && c->prm.iterations >= 1 && flow_iter_supported(c->prm.winsize);
+    const bool gauss = (c->prm.flags & OFARN_FLAG_FARNEBACK_GAUSSIAN) != 0;
+    const bool fused = !c->force_generic && !gauss && c->prm.iterations >= 1 && flow_iter_supported(c->prm.winsize);
     // Row pass of the level build for all levels that need one, in a single launch when their
     // tmp buffers fit side by side in the workspace; tmp_of[k] is where level k's rows went.
     const bool march0 = !c->force_generic && polyexp_march_supported(c->prm.poly_n);
@@ -436,7 +440,10 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
             });
         timed(c, s, OFARN_STAGE_MATRICES, k, upx, [&] { launch_update_matrices(s, ws.R, fstep, flow, ws.M, L.w, L.h, npairs); });
         for (int i = 0; i < c->prm.iterations; i++) {
-            timed(c, s, OFARN_STAGE_BLUR_SOLVE, k, upx, [&] { launch_blur_solve(s, ws.M, flow, L.w, L.h, npairs, c->prm.winsize); });
+            timed(c, s, OFARN_STAGE_BLUR_SOLVE, k, upx, [&] {
+                if (gauss) launch_gauss_solve(s, ws.M, flow, L.w, L.h, npairs, c->prm.winsize, c->d_gwin);
+                else launch_blur_solve(s, ws.M, flow, L.w, L.h, npairs, c->prm.winsize);
+            });
             if (i < c->prm.iterations - 1)
                 timed(c, s, OFARN_STAGE_MATRICES, k, upx, [&] { launch_update_matrices(s, ws.R, fstep, flow, ws.M, L.w, L.h, npairs); });
         }
@@ -471,6 +478,7 @@ int ensure_staging(ofarn_ctx *c, size_t frames_bytes, size_t flow_bytes, size_t 
     }
     if (flow_bytes > c->st_flow_cap) {
         if (c->st_flow) (void)hipFree(c->st_flow);
+    if (c->d_gwin) (void)hipFree(c->d_gwin);
         c->st_flow = nullptr; c->st_flow_cap = 0;
         HIP_TRY(hipMalloc((void **)&c->st_flow, flow_bytes));
         c->st_flow_cap = flow_bytes;
@@ -571,6 +579,24 @@ int ofarn_create(const ofarn_params *params, int device, int max_w, int max_h, i
     const size_t px = (size_t)max_w * max_h;
     c->tmp_floats = (size_t)2 * max_batch * px * 2;
     if (alloc_workspace(c, 0)) return bail(OFARN_E_NOMEM);
+    if (params->flags & OFARN_FLAG_FARNEBACK_GAUSSIAN) {
+        // FarnebackUpdateFlow_GaussianBlur: kernel[0] = 1, kernel[i] = (float)exp(-i*i/(2 sigma^2)), normalised
+        const int m = params->winsize / 2;
+        const double sigma = m * 0.3;
+        double sum = 1;
+        std::vector<float> k(m + 1);
+        k[0] = (float)sum;
+        for (int i = 1; i <= m; i++) {
+            const float t = (float)std::exp(-i * i / (2 * sigma * sigma));
+            k[i] = t;
+            sum += t * 2;
+        }
+        sum = 1. / sum;
+        for (int i = 0; i <= m; i++) k[i] = (float)(k[i] * sum);
+        if (hipMalloc((void **)&c->d_gwin, (m + 1) * sizeof(float)) != hipSuccess ||
+            hipMemcpy(c->d_gwin, k.data(), (m + 1) * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail(OFARN_E_HIP, "allocating the Gaussian window failed"));
+    }
     *out = c;
     return OFARN_OK;
 }
@@ -584,6 +610,7 @@ void ofarn_destroy(ofarn_ctx *c)
     for (auto &ws : c->ws)
         for (float *p : {ws.tmp, ws.I, ws.R, ws.M, ws.flowA, ws.flowB}) if (p) (void)hipFree(p);
     if (c->st_flow) (void)hipFree(c->st_flow);
+    if (c->d_gwin) (void)hipFree(c->d_gwin);
     for (int i = 0; i < 2; i++) {
         if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -932,7 +959,10 @@ int ofarn_stage_blur_solve(ofarn_ctx *c, const float *h_M, int w, int h, float *
     for (size_t o = 0; o < npx; o++)
         for (int ch = 0; ch < 5; ch++) mp[ch * npx + o] = h_M[o * 5 + ch];     // interleaved -> planar
     HIP_TRY(hipMemcpyAsync(c->ws[0].M, mp.data(), npx * 5 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    launch_blur_solve(c->stream, c->ws[0].M, c->ws[0].flowA, w, h, 1, c->prm.winsize);
+    if (c->prm.flags & OFARN_FLAG_FARNEBACK_GAUSSIAN)
+        launch_gauss_solve(c->stream, c->ws[0].M, c->ws[0].flowA, w, h, 1, c->prm.winsize, c->d_gwin);
+    else
+        launch_blur_solve(c->stream, c->ws[0].M, c->ws[0].flowA, w, h, 1, c->prm.winsize);
     HIP_TRY(hipMemcpyAsync(h_flow, c->ws[0].flowA, npx * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return OFARN_OK;

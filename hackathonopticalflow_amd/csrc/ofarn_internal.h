@@ -54,6 +54,9 @@ void launch_update_matrices(hipStream_t s, const float *R, int fstep, const floa
 void launch_blur_solve(hipStream_t s, const float *M, float *flow, int w, int h, int npairs,
                        int winsize);
 int blur_solve_max_winsize();
+// Stage D with the Gaussian window of OPTFLOW_FARNEBACK_GAUSSIAN; d_kern: m+1 taps (host formula of optflowgf.cpp)
+void launch_gauss_solve(hipStream_t s, const float *M, float *flow, int w, int h, int npairs, int winsize,
+                        const float *d_kern);
 // Stages (E+)C+D fused (kernels_fast.hip).  mode 0: zero input flow; 1: input flow is
 // upsample(coarse)*mul computed on the fly; 2: input flow read from flow_in.  flow_out != flow_in.
 bool flow_iter_supported(int winsize);

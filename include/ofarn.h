@@ -37,6 +37,9 @@ extern "C" {
 #define OFARN_E_SIZE (-5)      /* frame or batch larger than the context was created for         */
 
 /* pairs_mode of the batch entry points */
+/* flags (cv2 names OPTFLOW_*): only the Gaussian window is built; USE_INITIAL_FLOW (4) is SURVEY 8(f) */
+#define OFARN_FLAG_FARNEBACK_GAUSSIAN 256
+
 #define OFARN_PAIRS_INDEPENDENT 0 /* frames (2i, 2i+1) form pair i; n_pairs = n_frames/2          */
 #define OFARN_PAIRS_CONSECUTIVE 1 /* frames (i, i+1) form pair i (video order, DenseOF.py:525: */
                                   /* prev_gray = gray); n_pairs = n_frames-1                     */
@@ -50,7 +53,7 @@ typedef struct ofarn_params {
     int iterations;     /* per level                                  default 3   */
     int poly_n;         /* polynomial-expansion radius (2n+1 taps)    default 5   */
     double poly_sigma;  /*                                            default 1.2 */
-    int flags;          /* must be 0                                  default 0   */
+    int flags;          /* 0 or OFARN_FLAG_FARNEBACK_GAUSSIAN         default 0   */
     int grid_step;      /* danger-map grid step in pixels             default 30  */
     int filter_variant; /* 0: pathfinder_viewer.py:173  median < mod < P99   default 0   */
                         /* 1: DenseOF.py:228            mod > median * 1.2               */

@@ -546,6 +546,62 @@ OFO_API void ofo_update_flow_blur(const float *R0, const float *R1, float *flow_
     if (update_matrices) ofo_update_matrices(R0, R1, flow_, M, width, height, 0, height);
 }
 
+/* FarnebackUpdateFlow_GaussianBlur (flags & OPTFLOW_FARNEBACK_GAUSSIAN): the window is a separable
+ * Gaussian, sigma = m*0.3, m = winsize/2, all in float32 (only the 2x2 solve is double):
+ *   kernel[0] = 1, kernel[i] = (float)exp(-i*i/(2 sigma^2)); s = 1 + 2*sum (double); kernel[i] = (float)(kernel[i]/s... *(1/s))
+ *   column: s0 = M[y][x]*k[0]; s0 += (M[min(y+i,h-1)][x] + M[max(y-i,0)][x]) * k[i]       (i = 1..m)
+ *   row   : sum = v[x]*k[0];   sum += k[i] * (v[x-i] + v[x+i])   (replicate border)      (i = 1..m)
+ * followed by the same regularised solve.  Two-phase like ofo_update_flow_blur. */
+OFO_API void ofo_update_flow_gaussian(const float *R0, const float *R1, float *flow_, float *M,
+                                      int width, int height, int block_size, int update_matrices)
+{
+    const int m = block_size / 2;
+    double sigma = m * 0.3, s = 1;
+    float *kernel = (float *)malloc(sizeof(float) * (size_t)(m + 1));
+    kernel[0] = (float)s;
+    for (int i = 1; i <= m; i++) {
+        float t = (float)exp(-i * i / (2 * sigma * sigma));
+        kernel[i] = t;
+        s += t * 2;
+    }
+    s = 1. / s;
+    for (int i = 0; i <= m; i++) kernel[i] = (float)(kernel[i] * s);
+    float *_vsum = (float *)malloc(sizeof(float) * (size_t)(width + m * 2 + 2) * 5);
+    float *vsum = _vsum + (m + 1) * 5;
+    float *hsum = (float *)malloc(sizeof(float) * (size_t)width * 5);
+    for (int y = 0; y < height; y++) {
+        float *flow = flow_ + (size_t)y * width * 2;
+        const float *c = M + (size_t)y * width * 5;
+        for (int x = 0; x < width * 5; x++) {
+            float s0 = c[x] * kernel[0];
+            for (int i = 1; i <= m; i++) {
+                const float *a = M + (size_t)(y + i < height - 1 ? y + i : height - 1) * width * 5;
+                const float *b = M + (size_t)(y - i > 0 ? y - i : 0) * width * 5;
+                s0 += (a[x] + b[x]) * kernel[i];
+            }
+            vsum[x] = s0;
+        }
+        for (int x = 0; x < m * 5; x++) {
+            vsum[-1 - x] = vsum[4 - x];
+            vsum[width * 5 + x] = vsum[width * 5 + x - 5];
+        }
+        for (int x = 0; x < width * 5; x++) {
+            float sum = vsum[x] * kernel[0];
+            for (int i = 1; i <= m; i++) sum += kernel[i] * (vsum[x - i * 5] + vsum[x + i * 5]);
+            hsum[x] = sum;
+        }
+        for (int x = 0; x < width; x++) {
+            double g11 = hsum[x * 5], g12 = hsum[x * 5 + 1], g22 = hsum[x * 5 + 2];
+            double h1 = hsum[x * 5 + 3], h2 = hsum[x * 5 + 4];
+            double idet = 1. / (g11 * g22 - g12 * g12 + OFO_DET_EPS);
+            flow[x * 2] = (float)((g11 * h2 - g12 * h1) * idet);
+            flow[x * 2 + 1] = (float)((g22 * h1 - g12 * h2) * idet);
+        }
+    }
+    free(hsum); free(_vsum); free(kernel);
+    if (update_matrices) ofo_update_matrices(R0, R1, flow_, M, width, height, 0, height);
+}
+
 /* ------------------------------------------------------------------------- */
 /* A.2 the level loop                                                         */
 /* ------------------------------------------------------------------------- */
@@ -565,7 +621,7 @@ OFO_API int ofo_farneback_ex(const uint8_t *prev, const uint8_t *next, int W, in
 {
     if (!prev || !next || !flow0 || !p) return -1;
     if (!(p->pyr_scale < 1) || W <= 0 || H <= 0) return -2;
-    if (p->flags != 0) return -3;   /* USE_INITIAL_FLOW / FARNEBACK_GAUSSIAN: SURVEY 8(f) */
+    if (p->flags & ~256) return -3;   /* OPTFLOW_USE_INITIAL_FLOW (4) is not restated: SURVEY 8(f) */
     /* winsize < 2 gives m = 0, for which optflowgf.cpp's running-sum initialisation ((m+2) copies
      * of row 0) no longer describes a window at all (it yields M[y][x]+M[0][x]+M[y][0]+M[0][0]);
      * that artefact is not restated. */
@@ -607,9 +663,13 @@ OFO_API int ofo_farneback_ex(const uint8_t *prev, const uint8_t *next, int W, in
         float *M = (float *)malloc(sizeof(float) * npx * 5);
         ofo_update_matrices(R[0], R[1], flow, M, width, height, 0, height);
         if (cap && cap->M_first && cap->M_first[k]) memcpy(cap->M_first[k], M, sizeof(float) * npx * 5);
-        for (int i = 0; i < p->iterations; i++)
-            ofo_update_flow_blur(R[0], R[1], flow, M, width, height, p->winsize,
-                                 i < p->iterations - 1, box_mode);
+        for (int i = 0; i < p->iterations; i++) {
+            if (p->flags & 256)   /* OPTFLOW_FARNEBACK_GAUSSIAN */
+                ofo_update_flow_gaussian(R[0], R[1], flow, M, width, height, p->winsize, i < p->iterations - 1);
+            else
+                ofo_update_flow_blur(R[0], R[1], flow, M, width, height, p->winsize,
+                                     i < p->iterations - 1, box_mode);
+        }
         if (cap && cap->flow_out && cap->flow_out[k]) memcpy(cap->flow_out[k], flow, sizeof(float) * npx * 2);
         free(M); free(R[0]); free(R[1]);
         if (prevFlow) free(prevFlow);

@@ -80,6 +80,8 @@ def lib(omp: bool = False) -> C.CDLL:
         l.ofo_update_matrices.restype = None
         l.ofo_update_flow_blur.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         l.ofo_update_flow_blur.restype = None
+        l.ofo_update_flow_gaussian.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int]
+        l.ofo_update_flow_gaussian.restype = None
         l.ofo_farneback_ex.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.POINTER(OfoParams),
                                        C.c_int, fp, C.POINTER(OfoCapture)]
         l.ofo_farneback_ex.restype = C.c_int
@@ -189,6 +191,17 @@ def update_flow_blur(R0, R1, flow, M, winsize, update_matrices_flag, box_mode=BO
     h, w = flow.shape[:2]
     lib().ofo_update_flow_blur(_fp(R0), _fp(R1), _fp(flow), _fp(M), w, h, winsize,
                                int(bool(update_matrices_flag)), box_mode)
+    return flow, M
+
+
+def update_flow_gaussian(R0, R1, flow, M, winsize, update_matrices_flag):
+    """FarnebackUpdateFlow_GaussianBlur (OPTFLOW_FARNEBACK_GAUSSIAN).  Returns (new_flow, new_M)."""
+    R0 = np.ascontiguousarray(R0, np.float32)
+    R1 = np.ascontiguousarray(R1, np.float32)
+    flow = np.array(flow, np.float32, order="C", copy=True)
+    M = np.array(M, np.float32, order="C", copy=True)
+    h, w = flow.shape[:2]
+    lib().ofo_update_flow_gaussian(_fp(R0), _fp(R1), _fp(flow), _fp(M), w, h, winsize, int(bool(update_matrices_flag)))
     return flow, M
 
 

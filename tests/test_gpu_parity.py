@@ -211,6 +211,22 @@ def test_golden_fixtures(H, path):
     assert (v != g["v"]).sum() <= 1
 
 
+@pytest.mark.parametrize("w,h,kw", [(320, 240, dict(levels=2)), (333, 251, dict(levels=1, winsize=9, iterations=2)),
+                                    (200, 160, dict(levels=0, winsize=20))])
+def test_farneback_gaussian_flag(H, oracle, w, h, kw):
+    """flags=OPTFLOW_FARNEBACK_GAUSSIAN (256): FarnebackUpdateFlow_GaussianBlur, float32 separable window."""
+    prev, nxt, _ = translated_pair(h, w, 51, max_shift=5)
+    got = H.calculate_optical_flow(prev, nxt, flags=256, **kw)
+    np.testing.assert_array_equal(got, oracle.farneback(prev, nxt, flags=256, **kw))
+    rng = np.random.default_rng(5)
+    M = (rng.standard_normal((h, w, 5)) * 10).astype(np.float32)
+    z5, z2 = np.zeros_like(M), np.zeros((h, w, 2), np.float32)
+    ws = kw.get("winsize", 15)
+    ref, _ = oracle.update_flow_gaussian(z5, z5, z2, M, ws, False)
+    with H.FarnebackEngine(w, h, 1, winsize=ws, flags=256) as eng:
+        np.testing.assert_array_equal(eng.stage_blur_solve(M), ref)
+
+
 def test_constant_and_flow_reuse(H):
     img = np.full((96, 128), 200, np.uint8)
     out = np.full((96, 128, 2), 7, np.float32)
@@ -337,4 +353,4 @@ def test_argument_errors(H):
     with pytest.raises(ValueError):
         H.calculate_optical_flow(a, a, winsize=1)
     with pytest.raises(NotImplementedError):
-        H.calculate_optical_flow(a, a, flags=256)
+        H.calculate_optical_flow(a, a, flags=4)        # OPTFLOW_USE_INITIAL_FLOW: SURVEY 8(f)

@@ -63,6 +63,7 @@ def test_parameter_validation_without_gpu():
         p = H.make_params(**bad)
         assert lib.ofarn_level_plan(ctypes.byref(p), 640, 480, cap, arr, arr, arr, None) == ofarn.OFARN_E_INVALID
         assert lib.ofarn_last_error()
+    assert lib.ofarn_level_plan(ctypes.byref(H.make_params(flags=256)), 640, 480, cap, arr, arr, arr, None) == 4
     p = H.make_params(flags=4)
     assert lib.ofarn_level_plan(ctypes.byref(p), 640, 480, cap, arr, arr, arr, None) == ofarn.OFARN_E_UNSUPPORTED
 

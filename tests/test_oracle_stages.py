@@ -256,6 +256,31 @@ def test_solve_is_regularised_normal_equations(oracle):
     np.testing.assert_allclose(got[16, 16], [sol[1], sol[0]], rtol=1e-6)
 
 
+def test_gaussian_window_vs_scipy(oracle):
+    """OPTFLOW_FARNEBACK_GAUSSIAN: separable Gaussian (sigma = 0.3*(winsize/2)), replicate borders."""
+    rng = np.random.default_rng(2)
+    h, w, ws = 45, 52, 15
+    A = rng.standard_normal((h, w, 2, 2))
+    r4, r5, r6 = A[..., 0, 0], A[..., 1, 1], A[..., 0, 1]
+    r2, r3 = rng.standard_normal((2, h, w))
+    M = np.stack([r4 * r4 + r6 * r6, (r4 + r5) * r6, r5 * r5 + r6 * r6, r4 * r2 + r6 * r3, r6 * r2 + r5 * r3], -1).astype(np.float32)
+    m = ws // 2
+    x = np.arange(-m, m + 1)
+    k = np.exp(-x * x / (2 * (m * 0.3) ** 2))
+    k /= k.sum()
+    bl = np.stack([ndimage.correlate1d(ndimage.correlate1d(M[..., c].astype(np.float64), k, axis=0, mode="nearest"),
+                                       k, axis=1, mode="nearest") for c in range(5)], -1)
+    det = bl[..., 0] * bl[..., 2] - bl[..., 1] ** 2 + 1e-3
+    ref = np.stack([(bl[..., 0] * bl[..., 4] - bl[..., 1] * bl[..., 3]) / det,
+                    (bl[..., 2] * bl[..., 3] - bl[..., 1] * bl[..., 4]) / det], -1)
+    z5 = np.zeros_like(M)
+    got, _ = oracle.update_flow_gaussian(z5, z5, np.zeros((h, w, 2), np.float32), M, ws, False)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5)
+    p, n, (tx, ty) = translated_pair(240, 320, 9)
+    f = oracle.farneback(p, n, levels=2, flags=256)
+    assert np.linalg.norm(f[40:-40, 40:-40] - np.float32([tx, ty]), axis=-1).mean() < 0.15
+
+
 def test_constant_image_gives_zero_flow(oracle):
     img = np.full((64, 80), 77, np.uint8)
     flow = oracle.farneback(img, img, levels=1)
@@ -346,6 +371,6 @@ def test_rejects_bad_arguments(oracle):
     with pytest.raises(ValueError):
         oracle.farneback(p, n, pyr_scale=1.0)
     with pytest.raises(ValueError):
-        oracle.farneback(p, n, flags=4)
+        oracle.farneback(p, n, flags=4)       # OPTFLOW_USE_INITIAL_FLOW is not restated
     with pytest.raises(ValueError):
         oracle.farneback(p, n, winsize=1)
