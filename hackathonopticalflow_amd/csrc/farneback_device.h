@@ -137,8 +137,15 @@ __device__ __forceinline__ float border_x(int x, int w)
 __device__ __forceinline__ float border_ylo(int y) { return y < kBorder ? border_factor(y) : 1.f; }
 __device__ __forceinline__ float border_yhi(int y, int h) { return y >= h - kBorder ? border_factor(h - y - 1) : 1.f; }
 
-// bx = border_x(x, w) (a per-thread constant of a marching kernel); y is uniform across the block.
-__device__ __forceinline__ void matrices_finish(const GatherRaw &g, float bx, int h, int y, float out[5])
+// bx = border_x(x, w), ax = border_applies(x, w) (per-thread constants of a marching kernel); y is
+// uniform across the block.  optflowgf.cpp only scales when its unsigned range test fires, which for
+// images narrower than 2*BORDER is NOT the same as "within BORDER of an edge" -- kept literally.
+__device__ __forceinline__ bool border_applies(int v, int n)
+{
+    return (unsigned)(v - kBorder) >= (unsigned)(n - kBorder * 2);
+}
+
+__device__ __forceinline__ void matrices_finish(const GatherRaw &g, float bx, bool ax, int h, int y, float out[5])
 {
     const float dx = g.dx, dy = g.dy, fx = g.fx, fy = g.fy;
     const bool inb = g.inb != 0;
@@ -160,7 +167,7 @@ __device__ __forceinline__ void matrices_finish(const GatherRaw &g, float bx, in
     r3 = (g.r0[1] - r3) * 0.5f;
     r2 = r2 + (r4 * dy + r6 * dx);
     r3 = r3 + (r6 * dy + r5 * dx);
-    const float scale = (bx * border_ylo(y)) * border_yhi(y, h);
+    const float scale = (ax || border_applies(y, h)) ? (bx * border_ylo(y)) * border_yhi(y, h) : 1.f;
     r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
     out[0] = r4 * r4 + r6 * r6;
     out[1] = (r4 + r5) * r6;

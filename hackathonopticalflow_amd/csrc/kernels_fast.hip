@@ -101,6 +101,7 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
     const int x = blockIdx.x * OUTW - M_ + tid;
     const int xc = clampi(x, 0, w - 1);
     const float bx = border_x(xc, w);
+    const bool ax = border_applies(xc, w);
     const int y0 = blockIdx.y * strip_h;
     const int y1 = min(y0 + strip_h, h);
     const size_t npx = (size_t)w * h;
@@ -232,7 +233,7 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // attribute the whole load wait to segment 0
 #endif
         STAMP(0);
-        matrices_finish(raw, bx, h, row_of(t - M_), m);
+        matrices_finish(raw, bx, ax, h, row_of(t - M_), m);
         STAMP(1);
         {
             // vmcnt counts loads in issue order: the flow load goes FIRST in every step so that the

@@ -155,6 +155,16 @@ def test_generic_and_fused_paths_agree(H, oracle, monkeypatch):
         np.testing.assert_array_equal(H.calculate_optical_flow(prev, nxt, levels=1, iterations=iters), ref)
 
 
+@pytest.mark.parametrize("w,h", [(9, 7), (33, 17), (16, 64), (257, 3), (5, 300), (1, 1), (40, 1), (1, 40)])
+def test_degenerate_sizes(H, oracle, w, h):
+    rng = np.random.default_rng(w * 1000 + h)
+    prev = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    nxt = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    for kw in (dict(levels=3), dict(levels=0, winsize=5, iterations=2)):
+        got = H.calculate_optical_flow(prev, nxt, **kw)
+        np.testing.assert_array_equal(got, oracle.farneback(prev, nxt, box_mode=oracle.BOX_BLOCKED, **kw))
+
+
 def test_pipeline_1080p_L5_config2(H, oracle):
     """BASELINE config 2: one 1920x1080 pair, levels=5, iterations=3, seed 2001."""
     prev, nxt, (tx, ty) = translated_pair(1080, 1920, 2001)
