@@ -248,9 +248,10 @@ def main():
         "metric": "frame-pairs/s @1080p (5-level, 3-iter)", "value": round(value, 2), "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 (f64 accumulators)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"config3: 1920x1080 batch={B} translated smooth-noise pairs per GPU "
-                               f"({uniq} distinct, tiled), levels=5 iterations=3 winsize=15 poly_n=5, "
+                               f"({uniq} distinct, tiled), levels=5 iterations=3 winsize=15 poly_n=5, f32 with OpenCV's f64 "
+                               f"accumulators, "
                                f"flow + danger maps to HBM" + (", RCCL all-gather of danger maps" if world > 1 else ""),
                    "pairs_per_gpu": B, "global_pairs": B * world, "wave": min(args.wave, B),
                    "parallelism": f"pairs sharded over {world} GPU(s)"},
