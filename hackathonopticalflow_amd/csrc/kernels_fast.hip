@@ -31,6 +31,20 @@ namespace ofarn {
 
 constexpr int FI_THREADS = 256;
 
+// XCD-aware block remap (speed only): the dispatcher deals consecutive workgroup ids round-robin over
+// the 8 XCDs, each with its own L2.  Regrouping ids so that ids congruent mod 8 become a contiguous
+// range puts neighbouring column strips -- which read each other's halo columns -- behind the same L2.
+__device__ __forceinline__ void xcd_remap(unsigned &bx, unsigned &by, unsigned &bz)
+{
+    const unsigned nx = gridDim.x, ny = gridDim.y, nb = nx * ny * gridDim.z;
+    unsigned lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    if ((nb & 7u) == 0) lin = (lin & 7u) * (nb >> 3) + (lin >> 3);
+    bx = lin % nx;
+    const unsigned q = lin / nx;
+    by = q % ny;
+    bz = q / ny;
+}
+
 struct UpsampleArgs {
     const float2 *coarse;   // [P][ch][cw]
     int cw, ch;
@@ -98,14 +112,16 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
     __shared__ double sV[2][5][FI_THREADS];
 
     const int tid = threadIdx.x;
-    const int x = blockIdx.x * OUTW - M_ + tid;
+    unsigned bidx, bidy, bidz;
+    xcd_remap(bidx, bidy, bidz);
+    const int x = (int)bidx * OUTW - M_ + tid;
     const int xc = clampi(x, 0, w - 1);
     const float bx = border_x(xc, w);
     const bool ax = border_applies(xc, w);
-    const int y0 = blockIdx.y * strip_h;
+    const int y0 = (int)bidy * strip_h;
     const int y1 = min(y0 + strip_h, h);
     const size_t npx = (size_t)w * h;
-    const size_t p = blockIdx.z;
+    const size_t p = bidz;
     const float *R0 = R + p * fstep * r_frame_stride(npx);
     const float *R1 = R0 + r_frame_stride(npx);
     const float2 *fin = MODE == 2 ? flow_in + p * npx : nullptr;
