@@ -1,0 +1,235 @@
+// kernels_frontend.hip -- the steps either side of the dense-flow call:
+//
+//   k_bgr2gray     cv2.cvtColor(img, COLOR_BGR2GRAY) on uint8 frames        DenseOF.py:481,510
+//   k_resize_area  resize(flow0, INTER_AREA) * scale, the coarsest-level start of
+//                  OPTFLOW_USE_INITIAL_FLOW                                 optflowgf.cpp calc()
+//   k_flow_hsv     draw_hsv: direction -> hue, length -> value, HSV2BGR     DenseOF.py:109-124
+//   k_flow_arrows  draw_flow: step-14 sampling and int32 line end points    DenseOF.py:40-49
+//
+// All of them are HBM-bound byte/elementwise work; none is on the timed hot path of bench.py.
+#include "ofarn_internal.h"
+
+namespace ofarn {
+
+// ---------------------------------------------------------------------------------------------
+// BGR -> gray.  color_rgb.simd.hpp RGB2Gray<uchar>: (b*cb + g*cg + r*cr + (1 << (shift-1))) >> shift.
+// One thread converts 4 pixels: three aligned 4-byte loads (12 B) in, one 4-byte store out.
+__global__ __launch_bounds__(256) void k_bgr2gray(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ gray,
+                                                  size_t npx_total, int cb, int cg, int cr, int shift)
+{
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;   // group of 4 pixels
+    const size_t p0 = q * 4;
+    if (p0 >= npx_total) return;
+    const int half = 1 << (shift - 1);
+    if (p0 + 4 <= npx_total) {
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(bgr + p0 * 3);
+        const uint32_t a = s[0], b = s[1], c = s[2];   // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+        const int g0 = (int)((a & 255) * cb + ((a >> 8) & 255) * cg + ((a >> 16) & 255) * cr + half) >> shift;
+        const int g1 = (int)((a >> 24) * cb + (b & 255) * cg + ((b >> 8) & 255) * cr + half) >> shift;
+        const int g2 = (int)(((b >> 16) & 255) * cb + (b >> 24) * cg + (c & 255) * cr + half) >> shift;
+        const int g3 = (int)(((c >> 8) & 255) * cb + ((c >> 16) & 255) * cg + (c >> 24) * cr + half) >> shift;
+        *reinterpret_cast<uint32_t *>(gray + p0) = (uint32_t)g0 | ((uint32_t)g1 << 8) | ((uint32_t)g2 << 16) | ((uint32_t)g3 << 24);
+    } else {
+        for (size_t p = p0; p < npx_total; p++)
+            gray[p] = (uint8_t)((bgr[p * 3] * cb + bgr[p * 3 + 1] * cg + bgr[p * 3 + 2] * cr + half) >> shift);
+    }
+}
+
+// any alignment: one pixel per thread
+__global__ __launch_bounds__(256) void k_bgr2gray_bytes(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ gray,
+                                                        size_t npx_total, int cb, int cg, int cr, int shift)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npx_total) return;
+    gray[p] = (uint8_t)((bgr[p * 3] * cb + bgr[p * 3 + 1] * cg + bgr[p * 3 + 2] * cr + (1 << (shift - 1))) >> shift);
+}
+
+void launch_bgr2gray(hipStream_t s, const uint8_t *bgr, uint8_t *gray, size_t npx_total, int cb, int cg, int cr, int shift)
+{
+    if (npx_total == 0) return;
+    if ((((uintptr_t)bgr | (uintptr_t)gray) & 3) == 0) {
+        const size_t groups = (npx_total + 3) / 4;
+        hipLaunchKernelGGL(k_bgr2gray, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, bgr, gray, npx_total, cb, cg, cr, shift);
+    } else
+        hipLaunchKernelGGL(k_bgr2gray_bytes, dim3((unsigned)((npx_total + 255) / 256)), dim3(256), 0, s, bgr, gray, npx_total, cb, cg,
+                           cr, shift);
+}
+
+// ---------------------------------------------------------------------------------------------
+// resize(INTER_AREA) of 2-channel float flow, shrinking, followed by `flow *= scale`.
+// One thread per output element (pair, dy, dx, channel), accumulating in OpenCV's order:
+//   general (ResizeArea_Invoker): per source row of the cell  buf = 0; buf = buf + S*alpha (x table order);
+//                                 first row: sum = beta*buf, later rows: sum += beta*buf
+//   fast (ResizeAreaFast_Invoker, integer factors): sum += S0+S1+S2+S3 four cell pixels at a time, * 1/area
+// The source is read through L2 (neighbouring threads read neighbouring cells); this runs once per
+// pair at the coarsest scale only.
+struct AreaTab {
+    const int *xstart, *xsi;    // xstart[dw+1] -> entries of xsi / xalpha
+    const float *xalpha;
+    const int *ystart, *ysi;
+    const float *yalpha;
+    int fast, iscale_x, iscale_y;
+};
+
+__global__ __launch_bounds__(256) void k_resize_area(const float *__restrict__ src, int sw, int sh, float *__restrict__ dst,
+                                                     int dw, int dh, int npairs, AreaTab T, float mul)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t per_pair = (size_t)dw * dh * 2;
+    if (i >= per_pair * npairs) return;
+    const int p = (int)(i / per_pair);
+    const int r = (int)(i % per_pair);
+    const int c = r & 1, dx = (r >> 1) % dw, dy = (r >> 1) / dw;
+    const float *S0 = src + (size_t)p * sw * sh * 2 + c;
+    float v;
+    if (T.fast) {
+        const int area = T.iscale_x * T.iscale_y;
+        const float *S = S0 + ((size_t)dy * T.iscale_y * sw + (size_t)dx * T.iscale_x) * 2;
+        float sum = 0.f;
+        int k = 0;
+        for (; k <= area - 4; k += 4) {
+            const float a0 = S[((size_t)(k / T.iscale_x) * sw + (k % T.iscale_x)) * 2];
+            const float a1 = S[((size_t)((k + 1) / T.iscale_x) * sw + ((k + 1) % T.iscale_x)) * 2];
+            const float a2 = S[((size_t)((k + 2) / T.iscale_x) * sw + ((k + 2) % T.iscale_x)) * 2];
+            const float a3 = S[((size_t)((k + 3) / T.iscale_x) * sw + ((k + 3) % T.iscale_x)) * 2];
+            sum += a0 + a1 + a2 + a3;
+        }
+        for (; k < area; k++) sum += S[((size_t)(k / T.iscale_x) * sw + (k % T.iscale_x)) * 2];
+        v = sum * (1.f / (float)area);
+    } else {
+        float sum = 0.f;
+        const int x0 = T.xstart[dx], x1 = T.xstart[dx + 1];
+        for (int j = T.ystart[dy]; j < T.ystart[dy + 1]; j++) {
+            const float *S = S0 + (size_t)T.ysi[j] * sw * 2;
+            float buf = 0.f;
+            for (int k = x0; k < x1; k++) buf = buf + S[(size_t)T.xsi[k] * 2] * T.xalpha[k];
+            const float t = T.yalpha[j] * buf;
+            sum = j == T.ystart[dy] ? t : sum + t;
+        }
+        v = sum;
+    }
+    dst[i] = v * mul;
+}
+
+void launch_resize_area(hipStream_t s, const float *src, int sw, int sh, float *dst, int dw, int dh, int npairs,
+                        const AreaTabHost &t, float mul)
+{
+    const size_t n = (size_t)dw * dh * 2 * npairs;
+    if (n == 0) return;
+    AreaTab T{t.xstart, t.xsi, t.xalpha, t.ystart, t.ysi, t.yalpha, t.fast, t.iscale_x, t.iscale_y};
+    hipLaunchKernelGGL(k_resize_area, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, sw, sh, dst, dw, dh, npairs, T, mul);
+}
+
+// ---------------------------------------------------------------------------------------------
+// draw_hsv (DenseOF.py:109-124):
+//   ang = arctan2(fy, fx) + pi; v = sqrt(fx*fx + fy*fy)               float32 (NumPy 2 promotion)
+//   H = uint8(ang * (180/pi/2)); S = 255; V = uint8(minimum(v*4, 255))  truncating stores
+//   bgr = cvtColor(hsv, COLOR_HSV2BGR)                                 color_hsv.simd.hpp HSV2RGB_b
+// atan2f is the one transcendental here; a last-ulp difference from the host libm can move H by one
+// at a truncation boundary (tests allow that on the HSV plane and check HSV -> BGR bit for bit).
+__device__ __forceinline__ uint8_t sat_round_u8(float v)
+{
+    const float r = rintf(v);   // cvRound: half to even
+    return (uint8_t)(r < 0.f ? 0 : r > 255.f ? 255 : (int)r);
+}
+
+__device__ __forceinline__ void hsv2bgr_px(uint8_t H, uint8_t S, uint8_t V, uint8_t out[3])
+{
+    const float hscale = 6.f / 180.f;
+    float h = (float)H, s = (float)S * (1.f / 255.f), v = (float)V * (1.f / 255.f);
+    float b, g, r;
+    if (s == 0.f) {
+        b = g = r = v;
+    } else {
+        h *= hscale;
+        h = fmodf(h, 6.f);
+        int sector = (int)floorf(h);
+        h -= (float)sector;
+        if ((unsigned)sector >= 6u) { sector = 0; h = 0.f; }
+        const float t0 = v, t1 = v * (1.f - s), t2 = v * (1.f - s * h), t3 = v * (1.f - s * (1.f - h));
+        // sector_data = {1,3,0}, {1,0,2}, {3,0,1}, {0,2,1}, {0,1,3}, {2,1,0}  (b, g, r)
+        switch (sector) {
+        case 0: b = t1; g = t3; r = t0; break;
+        case 1: b = t1; g = t0; r = t2; break;
+        case 2: b = t3; g = t0; r = t1; break;
+        case 3: b = t0; g = t2; r = t1; break;
+        case 4: b = t0; g = t1; r = t3; break;
+        default: b = t2; g = t1; r = t0; break;
+        }
+    }
+    out[0] = sat_round_u8(b * 255.f);
+    out[1] = sat_round_u8(g * 255.f);
+    out[2] = sat_round_u8(r * 255.f);
+}
+
+__global__ __launch_bounds__(256) void k_flow_hsv(const float2 *__restrict__ flow, size_t npx, uint8_t *__restrict__ hsv,
+                                                  uint8_t *__restrict__ bgr)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npx) return;
+    const float2 f = flow[i];
+    const float ang = atan2f(f.y, f.x) + 3.14159274101257324f;           // float32(np.pi)
+    const float v = sqrtf(f.x * f.x + f.y * f.y);
+    const uint8_t H = (uint8_t)(int)(ang * 28.6478900909423828f);        // float32(180/np.pi/2)
+    const uint8_t V = (uint8_t)(int)fminf(v * 4.f, 255.f);
+    if (hsv) { hsv[i * 3] = H; hsv[i * 3 + 1] = 255; hsv[i * 3 + 2] = V; }
+    if (bgr) {
+        uint8_t o[3];
+        hsv2bgr_px(H, 255, V, o);
+        bgr[i * 3] = o[0]; bgr[i * 3 + 1] = o[1]; bgr[i * 3 + 2] = o[2];
+    }
+}
+
+void launch_flow_hsv(hipStream_t s, const float *flow, size_t npx, uint8_t *hsv, uint8_t *bgr)
+{
+    if (npx == 0) return;
+    hipLaunchKernelGGL(k_flow_hsv, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float2 *>(flow), npx, hsv, bgr);
+}
+
+__global__ __launch_bounds__(256) void k_hsv2bgr(const uint8_t *__restrict__ hsv, size_t npx, uint8_t *__restrict__ bgr)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npx) return;
+    uint8_t o[3];
+    hsv2bgr_px(hsv[i * 3], hsv[i * 3 + 1], hsv[i * 3 + 2], o);
+    bgr[i * 3] = o[0]; bgr[i * 3 + 1] = o[1]; bgr[i * 3 + 2] = o[2];
+}
+
+void launch_hsv2bgr(hipStream_t s, const uint8_t *hsv, size_t npx, uint8_t *bgr)
+{
+    if (npx == 0) return;
+    hipLaunchKernelGGL(k_hsv2bgr, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, hsv, npx, bgr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// draw_flow (DenseOF.py:40-49): y, x = mgrid[step/2:h:step, step/2:w:step].astype(int);
+// lines = int32(vstack([x, y, x - fx, y - fy]).T.reshape(-1, 2, 2) + 0.5).  x - fx is int64 - float32
+// = float64 in NumPy; int32() truncates toward zero.
+__global__ __launch_bounds__(256) void k_flow_arrows(const float2 *__restrict__ flow, int w, int h, int npairs, int nx, int ny,
+                                                     double start, double step, int32_t *__restrict__ lines)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t per = (size_t)nx * ny;
+    if (i >= per * npairs) return;
+    const int p = (int)(i / per), r = (int)(i % per);
+    const int iy = r / nx, ix = r % nx;                       // mgrid order: rows of y, x fastest
+    const int x = (int)(start + ix * step), y = (int)(start + iy * step);
+    const float2 f = flow[(size_t)p * w * h + (size_t)y * w + x];
+    int32_t *o = lines + i * 4;
+    o[0] = (int32_t)((double)x + 0.5);
+    o[1] = (int32_t)((double)y + 0.5);
+    o[2] = (int32_t)(((double)x - (double)f.x) + 0.5);
+    o[3] = (int32_t)(((double)y - (double)f.y) + 0.5);
+}
+
+void launch_flow_arrows(hipStream_t s, const float *flow, int w, int h, int npairs, int nx, int ny, double start, double step,
+                        int32_t *lines)
+{
+    const size_t n = (size_t)nx * ny * npairs;
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_flow_arrows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float2 *>(flow), w, h, npairs, nx, ny, start, step, lines);
+}
+
+}  // namespace ofarn

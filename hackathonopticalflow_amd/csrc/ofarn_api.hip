@@ -141,6 +141,29 @@ bool poly_prepare(int n, double sigma, PolyCoef &c)
     return true;
 }
 
+// computeResizeAreaTab -- resize.cpp: the source cells [dx*scale, (dx+1)*scale) with fractional end weights
+struct AreaAxis {
+    std::vector<int> start, si;
+    std::vector<float> alpha;
+};
+void area_axis(int ssize, int dsize, double scale, AreaAxis &t)
+{
+    t.start.assign(1, 0);
+    t.si.clear();
+    t.alpha.clear();
+    for (int dx = 0; dx < dsize; dx++) {
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cell = std::min(scale, ssize - fsx1);
+        int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+        sx2 = std::min(sx2, ssize - 1);
+        sx1 = std::min(sx1, sx2);
+        if (sx1 - fsx1 > 1e-3) { t.si.push_back(sx1 - 1); t.alpha.push_back((float)((sx1 - fsx1) / cell)); }
+        for (int sx = sx1; sx < sx2; sx++) { t.si.push_back(sx); t.alpha.push_back((float)(1.0 / cell)); }
+        if (fsx2 - sx2 > 1e-3) { t.si.push_back(sx2); t.alpha.push_back((float)(std::min(std::min(fsx2 - sx2, 1.), cell) / cell)); }
+        t.start.push_back((int)t.si.size());
+    }
+}
+
 struct Level {
     int w = 0, h = 0, ksize = 0;
     double sigma = 0;
@@ -199,8 +222,8 @@ int check_params(const ofarn_params *p)
     if (p->iterations < 0) return fail(OFARN_E_INVALID, "iterations must be >= 0, got %d", p->iterations);
     if (p->poly_n < 1 || p->poly_n > kMaxPolyN)
         return fail(OFARN_E_INVALID, "poly_n must be in [1, %d], got %d", kMaxPolyN, p->poly_n);
-    if (p->flags & ~OFARN_FLAG_FARNEBACK_GAUSSIAN)
-        return fail(OFARN_E_UNSUPPORTED, "flags=%d: only OPTFLOW_FARNEBACK_GAUSSIAN (256) is built; OPTFLOW_USE_INITIAL_FLOW (4) is not", p->flags);
+    if (p->flags & ~(OFARN_FLAG_FARNEBACK_GAUSSIAN | OFARN_FLAG_USE_INITIAL_FLOW))
+        return fail(OFARN_E_UNSUPPORTED, "flags=%d: only OPTFLOW_USE_INITIAL_FLOW (4) and OPTFLOW_FARNEBACK_GAUSSIAN (256) exist", p->flags);
     if ((p->flags & OFARN_FLAG_FARNEBACK_GAUSSIAN) && p->winsize / 2 > 60)
         return fail(OFARN_E_INVALID, "winsize must be <= 121 with OPTFLOW_FARNEBACK_GAUSSIAN, got %d", p->winsize);
     if (p->grid_step < 1) return fail(OFARN_E_INVALID, "grid_step must be >= 1, got %d", p->grid_step);
@@ -224,6 +247,8 @@ struct ofarn_ctx {
     std::vector<Level> lv;
     int *d_pts = nullptr;
     int P = 0;
+    AreaTabHost area;            // resize(INTER_AREA) full size -> coarsest level (OPTFLOW_USE_INITIAL_FLOW)
+    float init_scale = 1.f;      // pyr_scale ^ levels, as optflowgf.cpp accumulates it
     std::vector<void *> plan_allocs;
     // workspace
     // two workspaces: waves of one batch alternate between them on two internal streams, so the tail
@@ -235,6 +260,7 @@ struct ofarn_ctx {
     bool dual = true;            // OFARN_SINGLE_STREAM=1 disables the second workspace
     uint64_t ws_bytes = 0;
     size_t tmp_floats = 0;   // capacity of tmp in floats
+    uint8_t *gray[2] = {nullptr, nullptr};   // gray frames of a wave when the caller hands over BGR (lazy)
     // host-API staging (lazy)
     uint8_t *st_frames = nullptr;
     float *st_flow = nullptr;
@@ -274,6 +300,27 @@ int upload(ofarn_ctx *c, const std::vector<T> &v, T **out)
     return OFARN_OK;
 }
 
+// Device tables for resize(INTER_AREA) from sw x sh down to dw x dh (allocations owned by the plan).
+int build_area_tab(ofarn_ctx *c, int sw, int sh, int dw, int dh, AreaTabHost &out)
+{
+    if (dw > sw || dh > sh) return fail(OFARN_E_INVALID, "INTER_AREA is only built for shrinking (%dx%d -> %dx%d)", sw, sh, dw, dh);
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    const int isx = cv_round(scale_x), isy = cv_round(scale_y);      // saturate_cast<int>(double)
+    out = AreaTabHost();
+    out.fast = std::fabs(scale_x - isx) < DBL_EPSILON && std::fabs(scale_y - isy) < DBL_EPSILON;
+    out.iscale_x = isx;
+    out.iscale_y = isy;
+    if (out.fast) return OFARN_OK;
+    AreaAxis ax, ay;
+    area_axis(sw, dw, scale_x, ax);
+    area_axis(sh, dh, scale_y, ay);
+    int rc;
+    if ((rc = upload(c, ax.start, &out.xstart)) || (rc = upload(c, ax.si, &out.xsi)) || (rc = upload(c, ax.alpha, &out.xalpha)) ||
+        (rc = upload(c, ay.start, &out.ystart)) || (rc = upload(c, ay.si, &out.ysi)) || (rc = upload(c, ay.alpha, &out.yalpha)))
+        return rc;
+    return OFARN_OK;
+}
+
 int make_plan(ofarn_ctx *c, int w, int h)
 {
     if (c->plan_w == w && c->plan_h == h) return OFARN_OK;
@@ -307,6 +354,16 @@ int make_plan(ofarn_ctx *c, int w, int h)
         if ((rc = upload(c, ofs, &L.d_fxofs)) || (rc = upload(c, al, &L.d_fxa))) return rc;
         resize_tables(S.h, L.h, ofs, al);
         if ((rc = upload(c, ofs, &L.d_fyofs)) || (rc = upload(c, al, &L.d_fya))) return rc;
+    }
+    c->area = AreaTabHost();
+    c->init_scale = 1.f;
+    if ((c->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW) && nlev > 0) {
+        // resize(flow0, flow, Size(width, height), 0, 0, INTER_AREA); flow *= scale  (optflowgf.cpp calc(), coarsest level)
+        int rc;
+        if ((rc = build_area_tab(c, w, h, c->lv[nlev].w, c->lv[nlev].h, c->area))) return rc;
+        double scale = 1;
+        for (int i = 0; i < nlev; i++) scale *= c->prm.pyr_scale;
+        c->init_scale = (float)scale;
     }
     std::vector<int> xs, ys;
     axis_points(w, c->prm.grid_step, &xs);
@@ -345,8 +402,9 @@ inline void timed(ofarn_ctx *c, hipStream_t s, int stage, int level, double unit
 }
 
 // One wave: npairs <= max_batch pairs, frames already in HBM.
+// d_init (OPTFLOW_USE_INITIAL_FLOW): full-resolution start flows float[npairs][h][w][2]; may alias d_flow.
 int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, int pairs_mode, int w,
-             int h, float *d_flow, uint8_t *d_mask, uint8_t *d_v, int wi = 0)
+             int h, float *d_flow, uint8_t *d_mask, uint8_t *d_v, int wi = 0, const float *d_init = nullptr)
 {
     ofarn_ctx::Workspace &ws = c->ws[wi];
     const int fstep = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? 1 : 2;
@@ -382,6 +440,18 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
         } else
             for (auto &t : tmp_of) t = nullptr;
     }
+    // OPTFLOW_USE_INITIAL_FLOW: the coarsest level starts from resize(flow0, INTER_AREA) * scale instead of zero
+    const float *init_cur = nullptr;
+    if (d_init) {
+        const Level &Lc = c->lv[nlev];
+        if (nlev == 0)   // same size: resize() copies, scale = 1
+            HIP_TRY(hipMemcpyAsync(ws.flowA, d_init, fsz * 2 * sizeof(float) * npairs, hipMemcpyDeviceToDevice, s));
+        else
+            timed(c, s, OFARN_STAGE_INIT_FLOW, nlev, (double)Lc.w * Lc.h * npairs, [&] {
+                launch_resize_area(s, d_init, w, h, ws.flowA, Lc.w, Lc.h, npairs, c->area, c->init_scale);
+            });
+        init_cur = ws.flowA;
+    }
     for (int k = nlev; k >= 0; k--) {
         const Level &L = c->lv[k];
         const size_t npx = (size_t)L.w * L.h;
@@ -416,12 +486,12 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
             // stages (E +) C + D fused per iteration; flow ping-pongs between two buffers, the last
             // iteration of level 0 writes the caller's buffer.  The coarse flow is only read by
             // iteration 0, so its buffer is free again from iteration 1 on.
-            const float *cur = nullptr;
+            const float *cur = k == nlev ? init_cur : nullptr;
             for (int i = 0; i < c->prm.iterations; i++) {
-                const float *busy = i == 0 ? prev : cur;
+                const float *busy = (i == 0 && prev) ? prev : cur;
                 float *out = (i == c->prm.iterations - 1 && k == 0 && d_flow) ? d_flow
                              : (busy == ws.flowA ? ws.flowB : ws.flowA);
-                const int mode = i == 0 ? (prev ? 1 : 0) : 2;
+                const int mode = i == 0 ? (prev ? 1 : (cur ? 2 : 0)) : 2;
                 timed(c, s, OFARN_STAGE_FLOW_ITER, k, upx, [&] {
                     launch_flow_iter(s, ws.R, fstep, cur, out, L.w, L.h, npairs, c->prm.winsize, mode, prev, pw, ph,
                                      L.d_fxofs, L.d_fxa, L.d_fyofs, L.d_fya, mul);
@@ -432,7 +502,10 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
             continue;
         }
         float *flow = (k == 0 && d_flow) ? d_flow : (prev == ws.flowA ? ws.flowB : ws.flowA);
-        if (!prev) HIP_TRY(hipMemsetAsync(flow, 0, npx * 2 * sizeof(float) * npairs, s));
+        if (!prev && init_cur) {
+            if (flow != init_cur)
+                HIP_TRY(hipMemcpyAsync(flow, init_cur, npx * 2 * sizeof(float) * npairs, hipMemcpyDeviceToDevice, s));
+        } else if (!prev) HIP_TRY(hipMemsetAsync(flow, 0, npx * 2 * sizeof(float) * npairs, s));
         else
             timed(c, s, OFARN_STAGE_UPSAMPLE, k, upx, [&] {
                 launch_flow_upsample(s, prev, pw, ph, flow, L.w, L.h, npairs, L.d_fxofs, L.d_fxa, L.d_fyofs,
@@ -478,7 +551,6 @@ int ensure_staging(ofarn_ctx *c, size_t frames_bytes, size_t flow_bytes, size_t 
     }
     if (flow_bytes > c->st_flow_cap) {
         if (c->st_flow) (void)hipFree(c->st_flow);
-    if (c->d_gwin) (void)hipFree(c->d_gwin);
         c->st_flow = nullptr; c->st_flow_cap = 0;
         HIP_TRY(hipMalloc((void **)&c->st_flow, flow_bytes));
         c->st_flow_cap = flow_bytes;
@@ -616,7 +688,7 @@ void ofarn_destroy(ofarn_ctx *c)
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    for (uint8_t *p : {c->st_frames, c->st_mask, c->st_v}) if (p) (void)hipFree(p);
+    for (uint8_t *p : {c->st_frames, c->st_mask, c->st_v, c->gray[0], c->gray[1]}) if (p) (void)hipFree(p);
     for (auto &r : c->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : c->prof_free) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -701,8 +773,28 @@ int ofarn_grid_points(int w, int h, int step, float *h_pts)
     return (int)(xs.size() * ys.size());
 }
 
-int ofarn_calc_batch_device(ofarn_ctx *c, const uint8_t *d_frames, int n_frames, int w, int h, int pairs_mode,
-                            float *d_flow, uint8_t *d_mask, uint8_t *d_v, void *hip_stream)
+}  // extern "C"
+
+namespace {
+
+// gray staging for BGR input: 2 * max_batch frames per workspace
+int ensure_gray(ofarn_ctx *c, int wi)
+{
+    if (c->gray[wi]) return OFARN_OK;
+    const size_t bytes = (size_t)2 * c->max_batch * c->max_w * c->max_h + 256;
+    if (hipMalloc((void **)&c->gray[wi], bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(OFARN_E_NOMEM, "gray staging of %zu bytes does not fit", bytes);
+    }
+    c->ws_bytes += bytes;
+    return OFARN_OK;
+}
+
+// cv2.cvtColor(COLOR_BGR2GRAY) coefficients: color_rgb.simd.hpp RGB2Gray<uchar>, 15-bit fixed point (B, G, R)
+constexpr int kGrayB = 3735, kGrayG = 19235, kGrayR = 9798, kGrayShift = 15;
+
+int calc_batch_device_impl(ofarn_ctx *c, const uint8_t *d_frames, bool bgr, int n_frames, int w, int h, int pairs_mode,
+                           float *d_flow, uint8_t *d_mask, uint8_t *d_v, void *hip_stream)
 {
     int rc = check_size(c, w, h);
     if (rc) return rc;
@@ -713,15 +805,18 @@ int ofarn_calc_batch_device(ofarn_ctx *c, const uint8_t *d_frames, int n_frames,
     if (n_pairs < 0 || (pairs_mode == OFARN_PAIRS_INDEPENDENT && (n_frames & 1)))
         return fail(OFARN_E_INVALID, "n_frames=%d does not form whole pairs in mode %d", n_frames, pairs_mode);
     if (n_pairs == 0) return OFARN_OK;
+    const bool use_init = (c->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW) != 0;
+    if (use_init && !d_flow) return fail(OFARN_E_INVALID, "OPTFLOW_USE_INITIAL_FLOW needs the flow buffer (it holds the initial flow)");
     HIP_TRY(hipSetDevice(c->device));
     if ((rc = make_plan(c, w, h))) return rc;
     hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
     const size_t fsz = (size_t)w * h;
     const int fstep = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? 1 : 2;
     const int nwaves = (n_pairs + c->max_batch - 1) / c->max_batch;
+    if (bgr && (rc = ensure_gray(c, 0))) return rc;
     // More than one wave: alternate them over two internal streams (each with its own workspace), forked
     // from and joined back into the caller's stream with events.  Per-kernel profiling keeps one stream.
-    const bool dual = c->dual && nwaves > 1 && !c->prof_on && alloc_workspace(c, 1) == 0;
+    const bool dual = c->dual && nwaves > 1 && !c->prof_on && alloc_workspace(c, 1) == 0 && (!bgr || ensure_gray(c, 1) == 0);
     if (dual) {
         HIP_TRY(hipEventRecord(c->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
@@ -730,10 +825,21 @@ int ofarn_calc_batch_device(ofarn_ctx *c, const uint8_t *d_frames, int n_frames,
     int wi = 0;
     for (int p0 = 0; p0 < n_pairs; p0 += c->max_batch, wi ^= 1) {
         const int np = n_pairs - p0 < c->max_batch ? n_pairs - p0 : c->max_batch;
-        rc = run_wave(c, dual ? c->aux[wi] : s, d_frames + (size_t)p0 * fstep * fsz, np, pairs_mode, w, h,
-                      d_flow ? d_flow + (size_t)p0 * fsz * 2 : nullptr,
+        hipStream_t ws_stream = dual ? c->aux[wi] : s;
+        const uint8_t *wave_frames = d_frames + (size_t)p0 * fstep * fsz * (bgr ? 3 : 1);
+        if (bgr) {
+            // frame front end (DenseOF.py:481,510): BGR frames of this wave -> gray, then the usual path
+            const int nf = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? np + 1 : 2 * np;
+            uint8_t *g = c->gray[dual ? wi : 0];
+            timed(c, ws_stream, OFARN_STAGE_BGR2GRAY, 0, (double)nf * fsz, [&] {
+                launch_bgr2gray(ws_stream, wave_frames, g, (size_t)nf * fsz, kGrayB, kGrayG, kGrayR, kGrayShift);
+            });
+            wave_frames = g;
+        }
+        float *wave_flow = d_flow ? d_flow + (size_t)p0 * fsz * 2 : nullptr;
+        rc = run_wave(c, ws_stream, wave_frames, np, pairs_mode, w, h, wave_flow,
                       d_mask ? d_mask + (size_t)p0 * c->P : nullptr, d_v ? d_v + (size_t)p0 * c->P : nullptr,
-                      dual ? wi : 0);
+                      dual ? wi : 0, use_init ? wave_flow : nullptr);
         if (rc) return rc;
     }
     if (dual)
@@ -742,6 +848,201 @@ int ofarn_calc_batch_device(ofarn_ctx *c, const uint8_t *d_frames, int n_frames,
             HIP_TRY(hipStreamWaitEvent(s, c->ev_join[i], 0));
         }
     return OFARN_OK;
+}
+
+// device scratch that lives for one host-pointer call
+struct DevTmp {
+    void *p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+            return fail(OFARN_E_NOMEM, "device scratch of %zu bytes does not fit", bytes);
+        }
+        return OFARN_OK;
+    }
+    template <typename T> T *as() { return static_cast<T *>(p); }
+};
+
+// np.mgrid[step/2:size:step] (DenseOF.py:44): count and float start
+int arrow_axis(int size, int step, double *start)
+{
+    *start = step / 2.0;
+    const int n = (int)std::ceil((size - *start) / (step * 1.0));
+    return n < 0 ? 0 : n;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ofarn_calc_batch_device(ofarn_ctx *c, const uint8_t *d_frames, int n_frames, int w, int h, int pairs_mode,
+                            float *d_flow, uint8_t *d_mask, uint8_t *d_v, void *hip_stream)
+{
+    return calc_batch_device_impl(c, d_frames, false, n_frames, w, h, pairs_mode, d_flow, d_mask, d_v, hip_stream);
+}
+
+int ofarn_calc_batch_device_bgr(ofarn_ctx *c, const uint8_t *d_bgr, int n_frames, int w, int h, int pairs_mode,
+                                float *d_flow, uint8_t *d_mask, uint8_t *d_v, void *hip_stream)
+{
+    return calc_batch_device_impl(c, d_bgr, true, n_frames, w, h, pairs_mode, d_flow, d_mask, d_v, hip_stream);
+}
+
+int ofarn_bgr2gray_device(ofarn_ctx *c, const uint8_t *d_bgr, int n, int w, int h, uint8_t *d_gray, void *hip_stream)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    if (!d_bgr || !d_gray) return fail(OFARN_E_INVALID, "bgr and gray must not be NULL");
+    if (n < 0 || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad size n=%d %dx%d", n, w, h);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    launch_bgr2gray(s, d_bgr, d_gray, (size_t)n * w * h, kGrayB, kGrayG, kGrayR, kGrayShift);
+    HIP_TRY(hipGetLastError());
+    return OFARN_OK;
+}
+
+int ofarn_bgr2gray(ofarn_ctx *c, const uint8_t *h_bgr, int n, int w, int h, int stride, uint8_t *h_gray)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    if (!h_bgr || !h_gray) return fail(OFARN_E_INVALID, "bgr and gray must not be NULL");
+    if (n < 0 || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad size n=%d %dx%d", n, w, h);
+    if (stride < 3 * w) return fail(OFARN_E_INVALID, "stride %d < 3 * width %d", stride, w);
+    if (n == 0) return OFARN_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t npx = (size_t)w * h;
+    DevTmp in, out;
+    int rc;
+    if ((rc = in.alloc(npx * 3)) || (rc = out.alloc(npx))) return rc;
+    for (int i = 0; i < n; i++) {
+        HIP_TRY(hipMemcpy2DAsync(in.p, (size_t)w * 3, h_bgr + (size_t)i * stride * h, stride, (size_t)w * 3, h,
+                                 hipMemcpyHostToDevice, c->stream));
+        launch_bgr2gray(c->stream, in.as<uint8_t>(), out.as<uint8_t>(), npx, kGrayB, kGrayG, kGrayR, kGrayShift);
+        HIP_TRY(hipMemcpyAsync(h_gray + (size_t)i * npx, out.p, npx, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return OFARN_OK;
+}
+
+int ofarn_flow_hsv_device(ofarn_ctx *c, const float *d_flow, int n, int w, int h, uint8_t *d_hsv, uint8_t *d_bgr, void *hip_stream)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    if (!d_flow || (!d_hsv && !d_bgr)) return fail(OFARN_E_INVALID, "flow and at least one of hsv, bgr must not be NULL");
+    if (n < 0 || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad size n=%d %dx%d", n, w, h);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    launch_flow_hsv(s, d_flow, (size_t)n * w * h, d_hsv, d_bgr);
+    HIP_TRY(hipGetLastError());
+    return OFARN_OK;
+}
+
+int ofarn_flow_hsv(ofarn_ctx *c, const float *h_flow, int n, int w, int h, uint8_t *h_hsv, uint8_t *h_bgr)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    if (!h_flow || (!h_hsv && !h_bgr)) return fail(OFARN_E_INVALID, "flow and at least one of hsv, bgr must not be NULL");
+    if (n < 0 || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad size n=%d %dx%d", n, w, h);
+    if (n == 0) return OFARN_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t npx = (size_t)w * h;
+    DevTmp in, o1, o2;
+    int rc;
+    if ((rc = in.alloc(npx * 8)) || (rc = o1.alloc(npx * 3)) || (rc = o2.alloc(npx * 3))) return rc;
+    for (int i = 0; i < n; i++) {
+        HIP_TRY(hipMemcpyAsync(in.p, h_flow + (size_t)i * npx * 2, npx * 8, hipMemcpyHostToDevice, c->stream));
+        launch_flow_hsv(c->stream, in.as<float>(), npx, h_hsv ? o1.as<uint8_t>() : nullptr, h_bgr ? o2.as<uint8_t>() : nullptr);
+        if (h_hsv) HIP_TRY(hipMemcpyAsync(h_hsv + (size_t)i * npx * 3, o1.p, npx * 3, hipMemcpyDeviceToHost, c->stream));
+        if (h_bgr) HIP_TRY(hipMemcpyAsync(h_bgr + (size_t)i * npx * 3, o2.p, npx * 3, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return OFARN_OK;
+}
+
+int ofarn_hsv2bgr(ofarn_ctx *c, const uint8_t *h_hsv, size_t npx, uint8_t *h_bgr)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    if (!h_hsv || !h_bgr) return fail(OFARN_E_INVALID, "hsv and bgr must not be NULL");
+    if (npx == 0) return OFARN_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    DevTmp in, out;
+    int rc;
+    if ((rc = in.alloc(npx * 3)) || (rc = out.alloc(npx * 3))) return rc;
+    HIP_TRY(hipMemcpyAsync(in.p, h_hsv, npx * 3, hipMemcpyHostToDevice, c->stream));
+    launch_hsv2bgr(c->stream, in.as<uint8_t>(), npx, out.as<uint8_t>());
+    HIP_TRY(hipMemcpyAsync(h_bgr, out.p, npx * 3, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return OFARN_OK;
+}
+
+int ofarn_flow_arrow_count(int w, int h, int step, int *nx, int *ny)
+{
+    if (w < 1 || h < 1 || step < 1) return fail(OFARN_E_INVALID, "bad arrow grid arguments");
+    double st;
+    const int ax = arrow_axis(w, step, &st), ay = arrow_axis(h, step, &st);
+    if (nx) *nx = ax;
+    if (ny) *ny = ay;
+    return ax * ay;
+}
+
+int ofarn_flow_arrows_device(ofarn_ctx *c, const float *d_flow, int n, int w, int h, int step, int32_t *d_lines, void *hip_stream)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    if (!d_flow || !d_lines) return fail(OFARN_E_INVALID, "flow and lines must not be NULL");
+    if (n < 0 || w < 1 || h < 1 || step < 1) return fail(OFARN_E_INVALID, "bad arguments n=%d %dx%d step=%d", n, w, h, step);
+    HIP_TRY(hipSetDevice(c->device));
+    double st;
+    const int nx = arrow_axis(w, step, &st), ny = arrow_axis(h, step, &st);
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    launch_flow_arrows(s, d_flow, w, h, n, nx, ny, st, (double)step, d_lines);
+    HIP_TRY(hipGetLastError());
+    return OFARN_OK;
+}
+
+int ofarn_flow_arrows(ofarn_ctx *c, const float *h_flow, int n, int w, int h, int step, int32_t *h_lines)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    if (!h_flow || !h_lines) return fail(OFARN_E_INVALID, "flow and lines must not be NULL");
+    if (n < 0 || w < 1 || h < 1 || step < 1) return fail(OFARN_E_INVALID, "bad arguments n=%d %dx%d step=%d", n, w, h, step);
+    if (n == 0) return OFARN_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    double st;
+    const int nx = arrow_axis(w, step, &st), ny = arrow_axis(h, step, &st);
+    const size_t npx = (size_t)w * h, K = (size_t)nx * ny;
+    if (K == 0) return OFARN_OK;
+    DevTmp in, out;
+    int rc;
+    if ((rc = in.alloc(npx * 8)) || (rc = out.alloc(K * 4 * sizeof(int32_t)))) return rc;
+    for (int i = 0; i < n; i++) {
+        HIP_TRY(hipMemcpyAsync(in.p, h_flow + (size_t)i * npx * 2, npx * 8, hipMemcpyHostToDevice, c->stream));
+        launch_flow_arrows(c->stream, in.as<float>(), w, h, 1, nx, ny, st, (double)step, out.as<int32_t>());
+        HIP_TRY(hipMemcpyAsync(h_lines + (size_t)i * K * 4, out.p, K * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return OFARN_OK;
+}
+
+int ofarn_stage_resize_area(ofarn_ctx *c, const float *h_flow, int sw, int sh, int dw, int dh, float mul, float *h_out)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    if (!h_flow || !h_out) return fail(OFARN_E_INVALID, "NULL argument");
+    if (sw < 1 || sh < 1 || dw < 1 || dh < 1) return fail(OFARN_E_INVALID, "bad sizes");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t saved = c->plan_allocs.size();
+    AreaTabHost t;
+    int rc = build_area_tab(c, sw, sh, dw, dh, t);
+    DevTmp in, out;
+    if (!rc) rc = in.alloc((size_t)sw * sh * 8);
+    if (!rc) rc = out.alloc((size_t)dw * dh * 8);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(in.p, h_flow, (size_t)sw * sh * 8, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            launch_resize_area(c->stream, in.as<float>(), sw, sh, out.as<float>(), dw, dh, 1, t, mul);
+            e = hipMemcpyAsync(h_out, out.p, (size_t)dw * dh * 8, hipMemcpyDeviceToHost, c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(OFARN_E_HIP, "resize_area stage failed: %s", hipGetErrorString(e));
+    }
+    while (c->plan_allocs.size() > saved) { (void)hipFree(c->plan_allocs.back()); c->plan_allocs.pop_back(); }
+    return rc;
 }
 
 int ofarn_calc_batch(ofarn_ctx *c, const uint8_t *h_frames, int n_frames, int w, int h, int pairs_mode,
@@ -757,6 +1058,8 @@ int ofarn_calc_batch(ofarn_ctx *c, const uint8_t *h_frames, int n_frames, int w,
         return fail(OFARN_E_INVALID, "n_frames=%d does not form whole pairs in mode %d", n_frames, pairs_mode);
     if ((h_mask == nullptr) != (h_v == nullptr)) return fail(OFARN_E_INVALID, "danger mask and v must be given together");
     if (n_pairs == 0) return OFARN_OK;
+    const bool use_init = (c->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW) != 0;
+    if (use_init && !h_flow) return fail(OFARN_E_INVALID, "OPTFLOW_USE_INITIAL_FLOW needs the flow buffer (it holds the initial flow)");
     HIP_TRY(hipSetDevice(c->device));
     if ((rc = make_plan(c, w, h))) return rc;
     const size_t fsz = (size_t)w * h;
@@ -772,9 +1075,12 @@ int ofarn_calc_batch(ofarn_ctx *c, const uint8_t *h_frames, int n_frames, int w,
         const int nf = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? np + 1 : 2 * np;
         HIP_TRY(hipMemcpyAsync(c->st_frames, h_frames + (size_t)p0 * fstep * fsz, (size_t)nf * fsz,
                                hipMemcpyHostToDevice, c->stream));
+        if (use_init)
+            HIP_TRY(hipMemcpyAsync(c->st_flow, h_flow + (size_t)p0 * fsz * 2, (size_t)np * fsz * 2 * sizeof(float),
+                                   hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipEventRecord(c->ev0, c->stream));
         rc = run_wave(c, c->stream, c->st_frames, np, pairs_mode, w, h, c->st_flow, h_mask ? c->st_mask : nullptr,
-                      h_mask ? c->st_v : nullptr);
+                      h_mask ? c->st_v : nullptr, 0, use_init ? c->st_flow : nullptr);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(c->ev1, c->stream));
         if (h_flow)
@@ -805,8 +1111,13 @@ int ofarn_calc(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next, int w
     if ((rc = ensure_staging(c, 2 * fsz, fsz * 2 * sizeof(float), 0))) return rc;
     HIP_TRY(hipMemcpy2DAsync(c->st_frames, w, h_prev, stride, w, h, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpy2DAsync(c->st_frames + fsz, w, h_next, stride, w, h, hipMemcpyHostToDevice, c->stream));
+    const bool use_init = (c->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW) != 0;
+    if (use_init)   // cv2: `flow` is an in/out argument holding the initial flow
+        HIP_TRY(hipMemcpyAsync(c->st_flow, h_flow, fsz * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    if ((rc = run_wave(c, c->stream, c->st_frames, 1, OFARN_PAIRS_INDEPENDENT, w, h, c->st_flow, nullptr, nullptr))) return rc;
+    if ((rc = run_wave(c, c->stream, c->st_frames, 1, OFARN_PAIRS_INDEPENDENT, w, h, c->st_flow, nullptr, nullptr, 0,
+                       use_init ? c->st_flow : nullptr)))
+        return rc;
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipMemcpyAsync(h_flow, c->st_flow, fsz * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

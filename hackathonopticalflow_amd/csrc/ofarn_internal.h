@@ -90,4 +90,22 @@ int grid_filter_lds_bytes(int P);
 void launch_grid_filter(hipStream_t s, const float *flow, int w, int h, int npairs, const int *d_pts,
                         int P, int variant, uint8_t *mask, uint8_t *v, int32_t *iflow);
 
+// ---- front end / back end of the call (kernels_frontend.hip) ----
+// cv2.cvtColor(COLOR_BGR2GRAY) on n pixels of packed BGR; coefficients and shift from color_rgb.simd.hpp.
+void launch_bgr2gray(hipStream_t s, const uint8_t *bgr, uint8_t *gray, size_t npx_total, int cb, int cg, int cr, int shift);
+// resize(INTER_AREA) tables (device pointers), see k_resize_area
+struct AreaTabHost {
+    int *xstart = nullptr, *xsi = nullptr, *ystart = nullptr, *ysi = nullptr;
+    float *xalpha = nullptr, *yalpha = nullptr;
+    int fast = 0, iscale_x = 1, iscale_y = 1;
+};
+void launch_resize_area(hipStream_t s, const float *src, int sw, int sh, float *dst, int dw, int dh, int npairs,
+                        const AreaTabHost &t, float mul);
+// draw_hsv: flow -> HSV (optional) and BGR (optional), uint8 x 3 per pixel
+void launch_flow_hsv(hipStream_t s, const float *flow, size_t npx, uint8_t *hsv, uint8_t *bgr);
+void launch_hsv2bgr(hipStream_t s, const uint8_t *hsv, size_t npx, uint8_t *bgr);
+// draw_flow: int32 [npairs][ny*nx][2][2] line end points
+void launch_flow_arrows(hipStream_t s, const float *flow, int w, int h, int npairs, int nx, int ny, double start, double step,
+                        int32_t *lines);
+
 }  // namespace ofarn

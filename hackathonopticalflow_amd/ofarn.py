@@ -32,6 +32,9 @@ OFARN_E_HIP = -3
 OFARN_E_NOMEM = -4
 OFARN_E_SIZE = -5
 
+OPTFLOW_USE_INITIAL_FLOW = 4        # cv2 flag values
+OPTFLOW_FARNEBACK_GAUSSIAN = 256
+
 PAIRS_INDEPENDENT = 0   # frames (2i, 2i+1)
 PAIRS_CONSECUTIVE = 1   # frames (i, i+1): video order, DenseOF.py:525 (prev_gray = gray)
 
@@ -76,6 +79,19 @@ ABI = {
     "ofarn_stage_update_matrices": (C.c_int, [C.c_void_p, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
     "ofarn_stage_blur_solve": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, _fp]),
     "ofarn_stage_flow_upsample": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ofarn_stage_resize_area": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
+    "ofarn_bgr2gray": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p]),
+    "ofarn_bgr2gray_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ofarn_calc_batch_device_bgr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ofarn_flow_hsv": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, _u8p, _u8p]),
+    "ofarn_flow_hsv_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+    "ofarn_hsv2bgr": (C.c_int, [C.c_void_p, _u8p, C.c_size_t, _u8p]),
+    "ofarn_flow_arrow_count": (C.c_int, [C.c_int, C.c_int, C.c_int, _ip, _ip]),
+    "ofarn_flow_arrows": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
+    "ofarn_flow_arrows_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_void_p]),
 }
 
 
@@ -230,16 +246,25 @@ class FarnebackEngine:
         h, w = prev.shape
         if prev.strides[1] != 1 or prev.strides[0] != next.strides[0] or next.strides[1] != 1 or prev.strides[0] < w:
             prev, next = np.ascontiguousarray(prev), np.ascontiguousarray(next)
-        if not (isinstance(flow, np.ndarray) and flow.dtype == np.float32 and flow.shape == (h, w, 2)
-                and flow.flags.c_contiguous):
+        if self.params.flags & OPTFLOW_USE_INITIAL_FLOW:
+            # cv2: `flow` is in/out.  Written in place when it is a C-contiguous float32 array, else a copy is returned.
+            if flow is None:
+                raise ValueError("OPTFLOW_USE_INITIAL_FLOW needs `flow` (float32[H,W,2]) holding the initial flow")
+            f = np.asarray(flow)
+            if f.shape != (h, w, 2):
+                raise ValueError(f"flow must have shape {(h, w, 2)}, got {f.shape}")
+            flow = f if (f.dtype == np.float32 and f.flags.c_contiguous and f.flags.writeable) else \
+                np.array(f, np.float32, order="C")
+        elif not (isinstance(flow, np.ndarray) and flow.dtype == np.float32 and flow.shape == (h, w, 2)
+                  and flow.flags.c_contiguous):
             flow = np.empty((h, w, 2), np.float32)
         _check(self._lib.ofarn_calc(self._h, prev.ctypes.data_as(_u8p), next.ctypes.data_as(_u8p), w, h,
                                     prev.strides[0], flow.ctypes.data_as(_fp)))
         return flow
 
-    def calc_batch(self, frames, pairs_mode=PAIRS_INDEPENDENT, want_flow=True, want_danger=True):
+    def calc_batch(self, frames, pairs_mode=PAIRS_INDEPENDENT, want_flow=True, want_danger=True, init_flow=None):
         """frames uint8[n_frames,H,W] -> (flow float32[n_pairs,H,W,2] | None, mask u8[n_pairs,P] | None,
-        v u8[n_pairs,P] | None)."""
+        v u8[n_pairs,P] | None).  With OPTFLOW_USE_INITIAL_FLOW, init_flow float32[n_pairs,H,W,2] is required."""
         frames = np.asarray(frames)
         if frames.dtype != np.uint8 or frames.ndim != 3:
             raise ValueError("frames must be uint8[n_frames, H, W]")
@@ -248,6 +273,11 @@ class FarnebackEngine:
         n_pairs = n - 1 if pairs_mode == PAIRS_CONSECUTIVE else n // 2
         n_pairs = max(n_pairs, 0)
         flow = np.empty((n_pairs, h, w, 2), np.float32) if want_flow else None
+        if self.params.flags & OPTFLOW_USE_INITIAL_FLOW:
+            if init_flow is None or np.shape(init_flow) != (n_pairs, h, w, 2):
+                raise ValueError(f"OPTFLOW_USE_INITIAL_FLOW needs init_flow of shape {(n_pairs, h, w, 2)}")
+            flow = np.array(init_flow, np.float32, order="C")
+            want_flow = True
         P = len(grid_points(w, h, self.params.grid_step)) if want_danger else 0
         mask = np.zeros((n_pairs, P), np.uint8) if want_danger else None
         v = np.zeros((n_pairs, P), np.uint8) if want_danger else None
@@ -283,13 +313,81 @@ class FarnebackEngine:
 
     # ------------------------------------------------------------------ device-memory entry points
     def calc_batch_device(self, d_frames, n_frames, width, height, pairs_mode=PAIRS_INDEPENDENT,
-                          d_flow=None, d_mask=None, d_v=None, stream=None):
+                          d_flow=None, d_mask=None, d_v=None, stream=None, bgr=False):
         """Device-resident batch: arguments are torch CUDA tensors (or raw device addresses).
         Enqueues on `stream` (raw hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream;
-        None = the engine's own stream) and does not synchronise."""
-        _check(self._lib.ofarn_calc_batch_device(self._h, _ptr(d_frames), n_frames, width, height, pairs_mode,
-                                                 _ptr(d_flow), _ptr(d_mask), _ptr(d_v),
-                                                 C.c_void_p(stream) if stream else None))
+        None = the engine's own stream) and does not synchronise.  bgr=True: d_frames are decoded video
+        frames uint8[n_frames,H,W,3] and cv2.cvtColor(COLOR_BGR2GRAY) (DenseOF.py:510) runs on the device
+        in front of the flow.  With OPTFLOW_USE_INITIAL_FLOW d_flow holds the initial flows on entry."""
+        fn = self._lib.ofarn_calc_batch_device_bgr if bgr else self._lib.ofarn_calc_batch_device
+        _check(fn(self._h, _ptr(d_frames), n_frames, width, height, pairs_mode, _ptr(d_flow), _ptr(d_mask), _ptr(d_v),
+                  C.c_void_p(stream) if stream else None))
+
+    def bgr2gray_device(self, d_bgr, n, width, height, d_gray, stream=None):
+        _check(self._lib.ofarn_bgr2gray_device(self._h, _ptr(d_bgr), n, width, height, _ptr(d_gray),
+                                               C.c_void_p(stream) if stream else None))
+
+    def flow_hsv_device(self, d_flow, n, width, height, d_hsv=None, d_bgr=None, stream=None):
+        _check(self._lib.ofarn_flow_hsv_device(self._h, _ptr(d_flow), n, width, height, _ptr(d_hsv), _ptr(d_bgr),
+                                               C.c_void_p(stream) if stream else None))
+
+    def flow_arrows_device(self, d_flow, n, width, height, step, d_lines, stream=None):
+        _check(self._lib.ofarn_flow_arrows_device(self._h, _ptr(d_flow), n, width, height, step, _ptr(d_lines),
+                                                  C.c_void_p(stream) if stream else None))
+
+    # ------------------------------------------------------------------ front end and visualisers, host memory
+    def bgr2gray(self, img):
+        """cv2.cvtColor(img, cv2.COLOR_BGR2GRAY) for uint8[H,W,3] or a stack uint8[n,H,W,3] (DenseOF.py:481,510)."""
+        a = np.asarray(img)
+        if a.dtype != np.uint8 or a.ndim not in (3, 4) or a.shape[-1] != 3:
+            raise ValueError(f"img must be uint8[H,W,3] (or [n,H,W,3]), got {a.dtype}{a.shape}")
+        single = a.ndim == 3
+        a = np.ascontiguousarray(a[None] if single else a)
+        n, h, w, _ = a.shape
+        out = np.empty((n, h, w), np.uint8)
+        _check(self._lib.ofarn_bgr2gray(self._h, a.ctypes.data_as(_u8p), n, w, h, 3 * w, out.ctypes.data_as(_u8p)))
+        return out[0] if single else out
+
+    def flow_hsv(self, flow, return_hsv=False):
+        """draw_hsv (DenseOF.py:109-124): BGR uint8[H,W,3] rainbow of a flow field (or a stack of them)."""
+        f = np.ascontiguousarray(flow, np.float32)
+        single = f.ndim == 3
+        f = f[None] if single else f
+        n, h, w, two = f.shape
+        if two != 2:
+            raise ValueError("flow must be float32[..., H, W, 2]")
+        bgr = np.empty((n, h, w, 3), np.uint8)
+        hsv = np.empty((n, h, w, 3), np.uint8) if return_hsv else None
+        _check(self._lib.ofarn_flow_hsv(self._h, f.ctypes.data_as(_fp), n, w, h,
+                                        hsv.ctypes.data_as(_u8p) if return_hsv else None, bgr.ctypes.data_as(_u8p)))
+        if return_hsv:
+            return (bgr[0], hsv[0]) if single else (bgr, hsv)
+        return bgr[0] if single else bgr
+
+    def hsv2bgr(self, hsv):
+        """cv2.cvtColor(hsv, cv2.COLOR_HSV2BGR) on uint8[..., 3] (DenseOF.py:121)."""
+        a = np.ascontiguousarray(hsv, np.uint8)
+        if a.shape[-1] != 3:
+            raise ValueError("hsv must be uint8[..., 3]")
+        out = np.empty_like(a)
+        _check(self._lib.ofarn_hsv2bgr(self._h, a.ctypes.data_as(_u8p), a.size // 3, out.ctypes.data_as(_u8p)))
+        return out
+
+    def flow_arrows(self, flow, step=14):
+        """draw_flow's sampling (DenseOF.py:40-49): int32[K,2,2] line end points [[x, y], [x-fx, y-fy]]."""
+        f = np.ascontiguousarray(flow, np.float32)
+        single = f.ndim == 3
+        f = f[None] if single else f
+        n, h, w, two = f.shape
+        if two != 2:
+            raise ValueError("flow must be float32[..., H, W, 2]")
+        K = self._lib.ofarn_flow_arrow_count(w, h, int(step), None, None)
+        if K < 0:
+            _raise(K)
+        lines = np.zeros((n, K, 2, 2), np.int32)
+        _check(self._lib.ofarn_flow_arrows(self._h, f.ctypes.data_as(_fp), n, w, h, int(step),
+                                           lines.ctypes.data_as(C.POINTER(C.c_int32))))
+        return lines[0] if single else lines
 
     def danger_map_device(self, d_flow, n, width, height, d_mask, d_v, d_iflow=None, stream=None):
         _check(self._lib.ofarn_grid_filter_device(self._h, _ptr(d_flow), n, width, height, _ptr(d_mask),
@@ -297,14 +395,14 @@ class FarnebackEngine:
 
     # ------------------------------------------------------------------ per-kernel timing
     STAGES = ("level_hpass", "level_vpass", "polyexp", "flow_upsample", "update_matrices", "blur_solve",
-              "grid_filter", "flow_iter")
+              "grid_filter", "flow_iter", "bgr2gray", "init_flow")
 
     def profile_enable(self, on=True):
         _check(self._lib.ofarn_profile_enable(self._h, int(bool(on))))
 
     def profile_read(self):
         """[{stage, level, launches, ms, units}] since the last read (waits for the recorded events)."""
-        cap = 8 * 32
+        cap = len(self.STAGES) * 32
         st, lv, ln = (C.c_int * cap)(), (C.c_int * cap)(), (C.c_int * cap)()
         ms, un = (C.c_double * cap)(), (C.c_double * cap)()
         n = self._lib.ofarn_profile_read(self._h, cap, st, lv, ln, ms, un)
@@ -354,6 +452,14 @@ class FarnebackEngine:
         flow = np.empty((h, w, 2), np.float32)
         _check(self._lib.ofarn_stage_blur_solve(self._h, M.ctypes.data_as(_fp), w, h, flow.ctypes.data_as(_fp)))
         return flow
+
+    def stage_resize_area(self, flow, dw, dh, mul=1.0):
+        flow = np.ascontiguousarray(flow, np.float32)
+        sh, sw = flow.shape[:2]
+        out = np.empty((dh, dw, 2), np.float32)
+        _check(self._lib.ofarn_stage_resize_area(self._h, flow.ctypes.data_as(_fp), sw, sh, dw, dh, float(mul),
+                                                 out.ctypes.data_as(_fp)))
+        return out
 
     def stage_flow_upsample(self, flow, dw, dh):
         flow = np.ascontiguousarray(flow, np.float32)
@@ -406,6 +512,26 @@ def calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, itera
     """cv2.calcOpticalFlowFarneback with cv2's positional order (DenseOF.py:147-156)."""
     return calculate_optical_flow(prev, next, flow, pyr_scale, levels, winsize, iterations, poly_n,
                                   poly_sigma, flags)
+
+
+def cvtColor_bgr2gray(img, device=0):
+    """cv2.cvtColor(img, cv2.COLOR_BGR2GRAY) for uint8[H,W,3] (DenseOF.py:481, 510)."""
+    a = np.asarray(img)
+    if a.ndim != 3:
+        raise ValueError(f"img must be uint8[H,W,3], got shape {a.shape}")
+    return _engine_for(a.shape[0], a.shape[1], device).bgr2gray(a)
+
+
+def draw_hsv(flow_, device=0):
+    """Drop-in for DenseOF.py:109-124 ``draw_hsv``: BGR uint8[H,W,3], hue = direction, value = 4 x length."""
+    f = np.asarray(flow_)
+    return _engine_for(f.shape[0], f.shape[1], device).flow_hsv(f)
+
+
+def flow_lines(flow, step=14, device=0):
+    """The `lines` array of DenseOF.py:40-49 ``draw_flow`` (int32[K,2,2]); cv2.polylines draws them."""
+    f = np.asarray(flow)
+    return _engine_for(f.shape[0], f.shape[1], device).flow_arrows(f, step)
 
 
 def danger_map(flow, step=30, device=0, filter_variant=FILTER_VIEWER, return_flow=False):

@@ -36,10 +36,12 @@ extern "C" {
 #define OFARN_E_NOMEM (-4)     /* workspace does not fit                                         */
 #define OFARN_E_SIZE (-5)      /* frame or batch larger than the context was created for         */
 
-/* pairs_mode of the batch entry points */
-/* flags (cv2 names OPTFLOW_*): only the Gaussian window is built; USE_INITIAL_FLOW (4) is SURVEY 8(f) */
+/* flags (cv2 names OPTFLOW_*).  With USE_INITIAL_FLOW the flow buffer of every calc entry point is an
+ * in/out argument, as cv2's `flow` is: on entry it holds the full-resolution initial flow of each pair. */
+#define OFARN_FLAG_USE_INITIAL_FLOW 4
 #define OFARN_FLAG_FARNEBACK_GAUSSIAN 256
 
+/* pairs_mode of the batch entry points */
 #define OFARN_PAIRS_INDEPENDENT 0 /* frames (2i, 2i+1) form pair i; n_pairs = n_frames/2          */
 #define OFARN_PAIRS_CONSECUTIVE 1 /* frames (i, i+1) form pair i (video order, DenseOF.py:525: */
                                   /* prev_gray = gray); n_pairs = n_frames-1                     */
@@ -53,7 +55,7 @@ typedef struct ofarn_params {
     int iterations;     /* per level                                  default 3   */
     int poly_n;         /* polynomial-expansion radius (2n+1 taps)    default 5   */
     double poly_sigma;  /*                                            default 1.2 */
-    int flags;          /* 0 or OFARN_FLAG_FARNEBACK_GAUSSIAN         default 0   */
+    int flags;          /* 0 or an OR of OFARN_FLAG_*                 default 0   */
     int grid_step;      /* danger-map grid step in pixels             default 30  */
     int filter_variant; /* 0: pathfinder_viewer.py:173  median < mod < P99   default 0   */
                         /* 1: DenseOF.py:228            mod > median * 1.2               */
@@ -93,6 +95,36 @@ int ofarn_calc_batch_device(ofarn_ctx *ctx, const uint8_t *d_frames, int n_frame
                             int pairs_mode, float *d_flow, uint8_t *d_mask, uint8_t *d_v,
                             void *hip_stream);
 
+/* ---- frame front end ------------------------------------------------------
+ * cv2.cvtColor(img, cv2.COLOR_BGR2GRAY) on uint8 frames (DenseOF.py:481, 510): OpenCV 4.x fixed point,
+ * gray = (3735 B + 19235 G + 9798 R + 16384) >> 15.  h_bgr: n frames of h rows, `stride` bytes per row,
+ * 3 bytes per pixel; d_bgr: dense uint8[n][h][w][3].  Gray output dense uint8[n][h][w]. */
+int ofarn_bgr2gray(ofarn_ctx *ctx, const uint8_t *h_bgr, int n, int w, int h, int stride, uint8_t *h_gray);
+int ofarn_bgr2gray_device(ofarn_ctx *ctx, const uint8_t *d_bgr, int n, int w, int h, uint8_t *d_gray,
+                          void *hip_stream);
+/* ofarn_calc_batch_device on BGR video frames uint8[n_frames][h][w][3]: the conversion runs on the
+ * device per wave in front of the flow (replaces DenseOF.py:510 + :520 for a stack of decoded frames). */
+int ofarn_calc_batch_device_bgr(ofarn_ctx *ctx, const uint8_t *d_bgr, int n_frames, int w, int h,
+                                int pairs_mode, float *d_flow, uint8_t *d_mask, uint8_t *d_v,
+                                void *hip_stream);
+
+/* ---- dense visualisers ----------------------------------------------------
+ * draw_hsv (DenseOF.py:109-124): H = uint8((arctan2(fy, fx) + pi) * (180/pi/2)), S = 255,
+ * V = uint8(min(4 |f|, 255)), then cv2.cvtColor(hsv, COLOR_HSV2BGR).  flow float32[n][h][w][2];
+ * hsv and bgr uint8[n][h][w][3], either may be NULL. */
+int ofarn_flow_hsv(ofarn_ctx *ctx, const float *h_flow, int n, int w, int h, uint8_t *h_hsv, uint8_t *h_bgr);
+int ofarn_flow_hsv_device(ofarn_ctx *ctx, const float *d_flow, int n, int w, int h, uint8_t *d_hsv,
+                          uint8_t *d_bgr, void *hip_stream);
+/* cv2.cvtColor(hsv, cv2.COLOR_HSV2BGR) alone, uint8[npx][3] -> uint8[npx][3] (DenseOF.py:121). */
+int ofarn_hsv2bgr(ofarn_ctx *ctx, const uint8_t *h_hsv, size_t npx, uint8_t *h_bgr);
+/* draw_flow (DenseOF.py:40-49): the flow sampled on np.mgrid[step/2:h:step, step/2:w:step] and the
+ * int32 line end points [[x, y], [x - fx, y - fy]] (+0.5, truncated) that cv2.polylines receives.
+ * ofarn_flow_arrow_count returns K = ny * nx (rows of y, x fastest); lines int32[n][K][2][2]. */
+int ofarn_flow_arrow_count(int w, int h, int step, int *nx, int *ny);
+int ofarn_flow_arrows(ofarn_ctx *ctx, const float *h_flow, int n, int w, int h, int step, int32_t *h_lines);
+int ofarn_flow_arrows_device(ofarn_ctx *ctx, const float *d_flow, int n, int w, int h, int step,
+                             int32_t *d_lines, void *hip_stream);
+
 /* Measurement grid of pathfinder_viewer.py:255-267.  Returns P (number of points, x-major order);
  * if h_pts != NULL writes float32[P][2] = (x, y). */
 int ofarn_grid_points(int w, int h, int step, float *h_pts);
@@ -128,7 +160,9 @@ double ofarn_last_device_ms(const ofarn_ctx *ctx);
 #define OFARN_STAGE_BLUR_SOLVE 5  /* D: FarnebackUpdateFlow_Blur                        */
 #define OFARN_STAGE_GRID_FILTER 6 /* F: grid sample + vector filter + V                 */
 #define OFARN_STAGE_FLOW_ITER 7   /* (E+)C+D fused: one Farneback iteration, M stays on chip */
-#define OFARN_STAGE_COUNT 8
+#define OFARN_STAGE_BGR2GRAY 8    /* front end: cvtColor(COLOR_BGR2GRAY); units = pixels    */
+#define OFARN_STAGE_INIT_FLOW 9   /* USE_INITIAL_FLOW: resize(INTER_AREA) * scale           */
+#define OFARN_STAGE_COUNT 10
 int ofarn_profile_enable(ofarn_ctx *ctx, int on);
 int ofarn_profile_read(ofarn_ctx *ctx, int cap, int *stage, int *level, int *launches, double *ms,
                        double *units);
@@ -150,6 +184,9 @@ int ofarn_stage_update_matrices(ofarn_ctx *ctx, const float *h_R0, const float *
 int ofarn_stage_blur_solve(ofarn_ctx *ctx, const float *h_M, int w, int h, float *h_flow);
 int ofarn_stage_flow_upsample(ofarn_ctx *ctx, const float *h_flow, int sw, int sh, int dw, int dh,
                               float *h_out);
+/* resize(flow, INTER_AREA) * mul, shrinking only (the coarsest-level start of USE_INITIAL_FLOW) */
+int ofarn_stage_resize_area(ofarn_ctx *ctx, const float *h_flow, int sw, int sh, int dw, int dh, float mul,
+                            float *h_out);
 
 #ifdef __cplusplus
 }

@@ -616,12 +616,14 @@ typedef struct ofo_capture {
     float **flow_out;     /* [k] -> float[h][w][2]   flow leaving level k   */
 } ofo_capture;
 
+int ofo_resize_area(const float *src, int sw, int sh, int cn, float *dst, int dw, int dh);   /* frontend_oracle.c */
+
 OFO_API int ofo_farneback_ex(const uint8_t *prev, const uint8_t *next, int W, int H, int stride,
                              const ofo_params *p, int box_mode, float *flow0, const ofo_capture *cap)
 {
     if (!prev || !next || !flow0 || !p) return -1;
     if (!(p->pyr_scale < 1) || W <= 0 || H <= 0) return -2;
-    if (p->flags & ~256) return -3;   /* OPTFLOW_USE_INITIAL_FLOW (4) is not restated: SURVEY 8(f) */
+    if (p->flags & ~(256 | 4)) return -3;   /* OPTFLOW_FARNEBACK_GAUSSIAN | OPTFLOW_USE_INITIAL_FLOW */
     /* winsize < 2 gives m = 0, for which optflowgf.cpp's running-sum initialisation ((m+2) copies
      * of row 0) no longer describes a window at all (it yields M[y][x]+M[0][x]+M[y][0]+M[0][0]);
      * that artefact is not restated. */
@@ -635,7 +637,18 @@ OFO_API int ofo_farneback_ex(const uint8_t *prev, const uint8_t *next, int W, in
         ofo_level_geom(W, H, p->pyr_scale, k, &width, &height, &sigma, &smooth_sz);
         size_t npx = (size_t)width * height;
         float *flow = k > 0 ? (float *)malloc(sizeof(float) * npx * 2) : flow0;
-        if (!prevFlow) memset(flow, 0, sizeof(float) * npx * 2);
+        if (!prevFlow && (p->flags & 4)) {
+            /* OPTFLOW_USE_INITIAL_FLOW: resize(flow0, flow, Size(width, height), 0, 0, INTER_AREA); flow *= scale;
+             * flow0 is the caller's in/out buffer (read here at the coarsest level, written at level 0).
+             * Same size (k == 0): resize() copies onto itself and scale is 1. */
+            if (k > 0) {
+                double scale = 1;
+                for (int i = 0; i < k; i++) scale *= p->pyr_scale;
+                if (ofo_resize_area(flow0, W, H, 2, flow, width, height)) return -5;
+                const float mul = (float)scale;
+                for (size_t i = 0; i < npx * 2; i++) flow[i] = flow[i] * mul;
+            }
+        } else if (!prevFlow) memset(flow, 0, sizeof(float) * npx * 2);
         else {
             ofo_resize_linear(prevFlow, pw, ph, 2, flow, width, height);
             /* "flow *= 1./pyrScale_" on CV_32F is convertTo(-1, alpha): elem * (float)alpha */

@@ -43,7 +43,7 @@ class OfoCapture(C.Structure):
 def build(force: bool = False) -> None:
     """Compile the oracle with gcc (oracle/Makefile)."""
     so = os.path.join(_BUILD, "libofarn_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("farneback_oracle.c", "filter_oracle.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("farneback_oracle.c", "filter_oracle.c", "frontend_oracle.c", "Makefile")]
     if (not force and os.path.exists(so)
             and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs)
             and os.path.exists(os.path.join(_BUILD, "libofarn_oracle_omp.so"))):
@@ -97,6 +97,16 @@ def lib(omp: bool = False) -> C.CDLL:
         l.ofo_vector_filter2.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, u8p, fp,
                                          C.POINTER(C.c_int32), u8p, dp]
         l.ofo_vector_filter2.restype = C.c_int
+        l.ofo_gray_coeffs.argtypes = [C.c_int, ip, ip, ip, ip]
+        l.ofo_gray_coeffs.restype = None
+        l.ofo_bgr2gray.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
+        l.ofo_bgr2gray.restype = None
+        l.ofo_area_tab.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, fp]
+        l.ofo_area_tab.restype = C.c_int
+        l.ofo_resize_area.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int]
+        l.ofo_resize_area.restype = C.c_int
+        l.ofo_hsv2bgr_u8.argtypes = [u8p, C.c_size_t, u8p]
+        l.ofo_hsv2bgr_u8.restype = None
         _libs[omp] = l
     return _libs[omp]
 
@@ -217,9 +227,10 @@ class Capture:
 
 
 def farneback(prev, next, pyr_scale=0.5, levels=3, winsize=15, iterations=3, poly_n=5,
-              poly_sigma=1.2, flags=0, box_mode=BOX_RUNNING, capture=False):
-    """CPU oracle for cv2.calcOpticalFlowFarneback(prev, next, None, ...) -> float32[H,W,2].
+              poly_sigma=1.2, flags=0, box_mode=BOX_RUNNING, capture=False, init_flow=None):
+    """CPU oracle for cv2.calcOpticalFlowFarneback(prev, next, flow, ...) -> float32[H,W,2].
 
+    flags & 4 (OPTFLOW_USE_INITIAL_FLOW): init_flow float32[H,W,2] is cv2's in/out `flow` on entry.
     With capture=True also returns a Capture of per-level intermediates (index = level k)."""
     prev = np.ascontiguousarray(prev, np.uint8)
     next = np.ascontiguousarray(next, np.uint8)
@@ -227,6 +238,10 @@ def farneback(prev, next, pyr_scale=0.5, levels=3, winsize=15, iterations=3, pol
     H, W = prev.shape
     p = _params(pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags)
     flow = np.empty((H, W, 2), np.float32)
+    if flags & 4:
+        if init_flow is None or np.shape(init_flow) != (H, W, 2):
+            raise ValueError("OPTFLOW_USE_INITIAL_FLOW needs init_flow float32[H,W,2]")
+        flow = np.array(init_flow, np.float32, order="C")
     cap_struct = None
     cap = None
     if capture:
@@ -357,3 +372,75 @@ def danger_map_numpy(flow_hw2, width, height, step=30, variant=0, return_flow=Fa
     if return_flow:
         return mask.astype(np.uint8), v, iflow
     return mask.astype(np.uint8), v
+
+
+# --------------------------------------------------------------------------- front end and visualisers
+GRAY_15BIT = 0  # OpenCV >= 3.4.2 / 4.x
+GRAY_14BIT = 1  # older releases
+
+
+def bgr2gray(img_bgr, variant=GRAY_15BIT):
+    """cv2.cvtColor(img, cv2.COLOR_BGR2GRAY) on uint8[H,W,3] (DenseOF.py:481,510); C restatement."""
+    a = np.ascontiguousarray(img_bgr, np.uint8)
+    h, w, _ = a.shape
+    out = np.empty((h, w), np.uint8)
+    lib().ofo_bgr2gray(_u8p(a), w, h, 3 * w, variant, _u8p(out))
+    return out
+
+
+def area_tab(ssize, dsize):
+    cap = 2 * ssize + 2
+    si, di = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    al = np.zeros(cap, np.float32)
+    ip = C.POINTER(C.c_int)
+    n = lib().ofo_area_tab(ssize, dsize, cap, si.ctypes.data_as(ip), di.ctypes.data_as(ip), _fp(al))
+    return si[:n], di[:n], al[:n]
+
+
+def resize_area(src, dw, dh):
+    """cv::resize(src, (dw, dh), INTER_AREA), float32, shrinking only."""
+    src = np.ascontiguousarray(src, np.float32)
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    dst = np.empty((dh, dw) if src.ndim == 2 else (dh, dw, cn), np.float32)
+    rc = lib().ofo_resize_area(_fp(src), src.shape[1], src.shape[0], cn, _fp(dst), dw, dh)
+    if rc:
+        raise ValueError("resize_area: only shrinking is restated")
+    return dst
+
+
+def hsv2bgr_u8(hsv):
+    """cv2.cvtColor(hsv, cv2.COLOR_HSV2BGR) on uint8[...,3]; C restatement of HSV2RGB_b."""
+    a = np.ascontiguousarray(hsv, np.uint8)
+    out = np.empty_like(a)
+    lib().ofo_hsv2bgr_u8(_u8p(a), a.size // 3, _u8p(out))
+    return out
+
+
+def draw_hsv_planes_numpy(flow_):
+    """DenseOF.py:109-120, re-typed: the uint8 HSV image draw_hsv hands to cv2.cvtColor."""
+    h, w = flow_.shape[:2]
+    fx, fy = flow_[:, :, 0], flow_[:, :, 1]
+
+    ang = np.arctan2(fy, fx) + np.pi
+    v = np.sqrt(fx * fx + fy * fy)
+
+    hsv = np.zeros((h, w, 3), np.uint8)
+    hsv[..., 0] = ang * (180 / np.pi / 2)
+    hsv[..., 1] = 255
+    hsv[..., 2] = np.minimum(v * 4, 255)
+    return hsv
+
+
+def draw_hsv_numpy(flow_):
+    """draw_hsv (DenseOF.py:109-124): NumPy lines by the real NumPy, HSV2BGR by the C restatement."""
+    return hsv2bgr_u8(draw_hsv_planes_numpy(flow_))
+
+
+def draw_flow_lines_numpy(img_shape, flow, step=14):
+    """DenseOF.py:40-49, re-typed: the int32 `lines` array handed to cv2.polylines."""
+    h, w = img_shape
+    y, x = np.mgrid[step / 2:h:step, step / 2:w:step].reshape(2, -1).astype(int)
+    fx, fy = flow[y, x].T
+    lines = np.vstack([x, y, x - fx, y - fy]).T.reshape(-1, 2, 2)
+    lines = np.int32(lines + 0.5)
+    return lines

@@ -363,4 +363,143 @@ def test_argument_errors(H):
     with pytest.raises(ValueError):
         H.calculate_optical_flow(a, a, winsize=1)
     with pytest.raises(NotImplementedError):
-        H.calculate_optical_flow(a, a, flags=4)        # OPTFLOW_USE_INITIAL_FLOW: SURVEY 8(f)
+        H.calculate_optical_flow(a, a, flags=8)        # not a cv2 flag of this function
+    with pytest.raises(ValueError):
+        H.calculate_optical_flow(a, a, flags=4)        # OPTFLOW_USE_INITIAL_FLOW without `flow`
+
+
+# ------------------------------------------------------------------------------------ front end
+@pytest.mark.parametrize("h,w", [(120, 160), (37, 53), (1, 1), (3, 5), (1080, 1920)])
+def test_bgr2gray_bit_exact(H, oracle, h, w):
+    rng = np.random.default_rng(h * 7 + w)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(H.cvtColor_bgr2gray(img), oracle.bgr2gray(img))
+    with H.FarnebackEngine(w, h, 1) as eng:
+        stack = rng.integers(0, 256, (3, h, w, 3), dtype=np.uint8)
+        got = eng.bgr2gray(stack)
+        for i in range(3):
+            np.testing.assert_array_equal(got[i], oracle.bgr2gray(stack[i]))
+        # a view with a row stride (cv2 accepts it): the mirror copies
+        wide = rng.integers(0, 256, (h, w + 3, 3), dtype=np.uint8)
+        np.testing.assert_array_equal(eng.bgr2gray(wide[:, :w]), oracle.bgr2gray(np.ascontiguousarray(wide[:, :w])))
+
+
+def test_bgr_video_batch_device(H, oracle):
+    torch = pytest.importorskip("torch")
+    h, w, n_frames = 97, 131, 6         # odd sizes: frame offsets are not 4-byte aligned (byte kernel)
+    rng = np.random.default_rng(77)
+    gray, _ = translated_pairs(n_frames // 2, h, w, 5100, max_shift=3)
+    # colour frames whose gray conversion is not trivially one channel
+    bgr = np.stack([gray, np.roll(gray, 1, axis=2), 255 - gray], -1)
+    bgr = (bgr.astype(np.int16) + rng.integers(-3, 4, bgr.shape)).clip(0, 255).astype(np.uint8)
+    g_ref = np.stack([oracle.bgr2gray(f) for f in bgr])
+    d_bgr = torch.from_numpy(bgr).cuda()
+    for mode, n_pairs in ((H.PAIRS_CONSECUTIVE, n_frames - 1), (H.PAIRS_INDEPENDENT, n_frames // 2)):
+        d_flow = torch.empty((n_pairs, h, w, 2), dtype=torch.float32, device="cuda")
+        with H.FarnebackEngine(w, h, 2, levels=1) as eng:          # waves of 2 pairs: several waves, two streams
+            eng.calc_batch_device(d_bgr, n_frames, w, h, mode, d_flow, None, None,
+                                  stream=torch.cuda.current_stream().cuda_stream, bgr=True)
+            torch.cuda.synchronize()
+            d_gray = torch.empty((n_frames, h, w), dtype=torch.uint8, device="cuda")
+            eng.bgr2gray_device(d_bgr, n_frames, w, h, d_gray, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+        np.testing.assert_array_equal(d_gray.cpu().numpy(), g_ref)
+        flow = d_flow.cpu().numpy()
+        for i in range(n_pairs):
+            a, b = (g_ref[i], g_ref[i + 1]) if mode == H.PAIRS_CONSECUTIVE else (g_ref[2 * i], g_ref[2 * i + 1])
+            np.testing.assert_array_equal(flow[i], oracle.farneback(a, b, levels=1, box_mode=oracle.BOX_BLOCKED))
+
+
+# ------------------------------------------------------------------------------------ USE_INITIAL_FLOW
+@pytest.mark.parametrize("sw,sh,dw,dh", [(480, 270, 15, 9), (250, 130, 8, 5), (97, 83, 13, 11), (256, 128, 8, 4),
+                                         (90, 60, 30, 20), (64, 32, 32, 16), (77, 33, 11, 33), (1920, 1080, 60, 34)])
+def test_stage_resize_area_bit_exact(H, oracle, sw, sh, dw, dh):
+    rng = np.random.default_rng(sw + dh)
+    src = (rng.standard_normal((sh, sw, 2)) * 3).astype(np.float32)
+    with H.FarnebackEngine(sw, sh, 1) as eng:
+        got = eng.stage_resize_area(src, dw, dh, 0.03125)
+    np.testing.assert_array_equal(got, oracle.resize_area(src, dw, dh) * np.float32(0.03125))
+
+
+@pytest.mark.parametrize("w,h,kw", [(320, 240, dict(levels=3)), (333, 251, dict(levels=2, winsize=9, iterations=2)),
+                                    (160, 120, dict(levels=0)), (200, 150, dict(levels=1, iterations=1)),
+                                    (256, 192, dict(levels=2, flags=256))])
+def test_use_initial_flow(H, oracle, w, h, kw, monkeypatch):
+    kw = dict(kw)
+    flags = kw.pop("flags", 0) | H.OPTFLOW_USE_INITIAL_FLOW
+    a, b, (tx, ty) = translated_pair(h, w, 31, max_shift=4)
+    rng = np.random.default_rng(6)
+    init = (np.array([tx, ty], np.float32) + rng.standard_normal((h, w, 2)).astype(np.float32) * 0.5).astype(np.float32)
+    ref = oracle.farneback(a, b, flags=flags, init_flow=init, box_mode=oracle.BOX_BLOCKED, **kw)
+    buf = init.copy()
+    got = H.calculate_optical_flow(a, b, buf, flags=flags, **kw)
+    assert got is buf                                   # cv2 semantics: `flow` is written in place
+    np.testing.assert_array_equal(got, ref)
+    # the start matters (otherwise this test proves nothing)
+    assert not np.array_equal(ref, oracle.farneback(a, b, flags=flags & 256, box_mode=oracle.BOX_BLOCKED, **kw))
+    # unfused kernels take the same start
+    monkeypatch.setenv("OFARN_FORCE_GENERIC", "1")
+    with H.FarnebackEngine(w, h, 1, flags=flags, **kw) as eng:
+        np.testing.assert_array_equal(eng.calc(a, b, init.copy()), ref)
+    monkeypatch.delenv("OFARN_FORCE_GENERIC")
+    with pytest.raises(ValueError):
+        H.calculate_optical_flow(a, b, None, flags=flags, **kw)
+
+
+def test_use_initial_flow_batch(H, oracle):
+    torch = pytest.importorskip("torch")
+    h, w, n_pairs = 120, 160, 5
+    frames, shifts = translated_pairs(n_pairs, h, w, 6100, max_shift=4)
+    init = np.zeros((n_pairs, h, w, 2), np.float32)
+    init[...] = np.asarray(shifts, np.float32)[:, None, None, :]
+    ref = [oracle.farneback(frames[2 * i], frames[2 * i + 1], levels=2, flags=4, init_flow=init[i], box_mode=oracle.BOX_BLOCKED)
+           for i in range(n_pairs)]
+    with H.FarnebackEngine(w, h, 2, levels=2, flags=4) as eng:
+        flow, _, _ = eng.calc_batch(frames, H.PAIRS_INDEPENDENT, init_flow=init)
+        for i in range(n_pairs):
+            np.testing.assert_array_equal(flow[i], ref[i])
+        d_flow = torch.from_numpy(init).cuda()                      # in/out on the device, several waves
+        eng.calc_batch_device(torch.from_numpy(frames).cuda(), 2 * n_pairs, w, h, H.PAIRS_INDEPENDENT, d_flow, None, None)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(d_flow.cpu().numpy(), np.stack(ref))
+        with pytest.raises(ValueError):
+            eng.calc_batch(frames, H.PAIRS_INDEPENDENT)
+        with pytest.raises(ValueError):
+            eng.calc_batch_device(torch.from_numpy(frames).cuda(), 2 * n_pairs, w, h, H.PAIRS_INDEPENDENT, None, None, None)
+
+
+# ------------------------------------------------------------------------------------ visualisers
+def test_hsv2bgr_bit_exact(H, oracle):
+    Hh, S, V = np.meshgrid(np.arange(0, 256, 1), np.arange(0, 256, 5), np.arange(0, 256, 3), indexing="ij")
+    hsv = np.stack([Hh, S, V], -1).astype(np.uint8).reshape(-1, 3)
+    with H.FarnebackEngine(8, 8, 1) as eng:
+        np.testing.assert_array_equal(eng.hsv2bgr(hsv), oracle.hsv2bgr_u8(hsv))
+
+
+@pytest.mark.parametrize("h,w", [(120, 160), (1080, 1920)])
+def test_draw_hsv(H, oracle, h, w):
+    rng = np.random.default_rng(12)
+    flow = (rng.standard_normal((h, w, 2)) * 20).astype(np.float32)
+    flow[0, :8] = [(1, 0), (-1, 0), (0, 1), (0, -1), (0, 0), (-3, -0.0), (100, 100), (1e-20, -1e-20)]
+    with H.FarnebackEngine(w, h, 1) as eng:
+        bgr, hsv = eng.flow_hsv(flow, return_hsv=True)
+    np.testing.assert_array_equal(H.draw_hsv(flow), bgr)
+    ref_hsv = oracle.draw_hsv_planes_numpy(flow)
+    # S and V exact; H exact except where atan2f differs in the last ulp just at a truncation boundary
+    np.testing.assert_array_equal(hsv[..., 1:], ref_hsv[..., 1:])
+    dh = np.abs(hsv[..., 0].astype(int) - ref_hsv[..., 0].astype(int))
+    assert dh.max() <= 1 and (dh != 0).mean() <= 1e-4, (dh.max(), (dh != 0).mean())
+    # HSV -> BGR (OpenCV's arithmetic) is bit-exact on the device's own HSV plane
+    np.testing.assert_array_equal(bgr, oracle.hsv2bgr_u8(hsv))
+    same = dh == 0
+    np.testing.assert_array_equal(bgr[same], oracle.draw_hsv_numpy(flow)[same])
+
+
+@pytest.mark.parametrize("h,w,step", [(120, 160, 14), (1080, 1920, 14), (100, 150, 15), (20, 20, 30), (5, 5, 14)])
+def test_draw_flow_lines_bit_exact(H, oracle, h, w, step):
+    rng = np.random.default_rng(13)
+    flow = (rng.standard_normal((h, w, 2)) * 9).astype(np.float32)
+    ref = oracle.draw_flow_lines_numpy((h, w), flow, step)
+    got = H.flow_lines(flow, step)
+    assert got.dtype == np.int32 and got.shape == ref.shape
+    np.testing.assert_array_equal(got, ref)

@@ -64,8 +64,12 @@ def test_parameter_validation_without_gpu():
         assert lib.ofarn_level_plan(ctypes.byref(p), 640, 480, cap, arr, arr, arr, None) == ofarn.OFARN_E_INVALID
         assert lib.ofarn_last_error()
     assert lib.ofarn_level_plan(ctypes.byref(H.make_params(flags=256)), 640, 480, cap, arr, arr, arr, None) == 4
-    p = H.make_params(flags=4)
+    assert lib.ofarn_level_plan(ctypes.byref(H.make_params(flags=4 | 256)), 640, 480, cap, arr, arr, arr, None) == 4
+    p = H.make_params(flags=8)      # not a flag of cv2.calcOpticalFlowFarneback
     assert lib.ofarn_level_plan(ctypes.byref(p), 640, 480, cap, arr, arr, arr, None) == ofarn.OFARN_E_UNSUPPORTED
+    nx, ny = ctypes.c_int(), ctypes.c_int()
+    assert lib.ofarn_flow_arrow_count(1920, 1080, 14, ctypes.byref(nx), ctypes.byref(ny)) == 137 * 77   # DenseOF.py:44
+    assert (nx.value, ny.value) == (137, 77)
 
 
 def test_input_validation_before_any_device_call():
