@@ -29,6 +29,12 @@
  *
  * Three summation orders are offered for the winsize x winsize box average
  * (OFO_BOX_RUNNING / OFO_BOX_DIRECT / OFO_BOX_BLOCKED); see ofo_update_flow_blur().
+ *
+ * Known nuance that is NOT restated: for a level exactly half the frame in both directions
+ * cv::resize() swaps INTER_LINEAR for the 2x2 INTER_AREA fast path.  Its vector form,
+ * ((a+b)+(c+d))*0.25, rounds exactly like the bilinear form with weights 1/2 used here, but the
+ * scalar tail of a row (the last (W/2) mod 4 columns) sums ((a+b)+c)+d.  Frame widths with
+ * (W/2) mod 4 == 0 (640, 1920, 3840) are unaffected.
  */
 #include <math.h>
 #include <stdint.h>
