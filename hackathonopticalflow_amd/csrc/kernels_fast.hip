@@ -15,8 +15,8 @@
 //     each other's halo columns, so the update cannot be in place.
 //
 // Summation order is the oracle's OFO_BOX_BLOCKED order (column sums: running sums in double
-// restarted every 2m+1 rows; then columns x-m..x+m left to right in double), so results equal the
-// unfused generic kernels and the CPU oracle bit for bit.
+// restarted every 2m+1 rows; then columns x-m..x+m in chunks of three, left to right, in double), so
+// results equal the unfused generic kernels and the CPU oracle bit for bit.
 //
 // Roofline: HBM-bound by design: per pixel and iteration it reads flow 8 B + R0 20 B + R1 20 B
 // (gathered, mostly sequential) and writes 8 B, x (256/(256-2m)) x ((strip_h+2m)/strip_h) halo
@@ -100,6 +100,22 @@ constexpr int FI_REGCH = OFARN_FI_REGCH;
 #else
 #define STAMP(k) do { } while (0)
 #endif   // channels whose row FIFO lives in registers
+
+// OFARN_HSUM3: horizontal pass in chunks of three columns.  t3[x] = (V[x] + V[x+1]) + V[x+2] is formed in
+// registers with two whole-wave DPP shifts (v_mov_b32_dpp wave_shl:1; the two lanes at a wave's end take
+// the next wave's first two values from a tiny LDS edge buffer), written to an LDS line, and the window
+// sum is ((((t3[x-m] + t3[x-m+3]) + ...) five reads for m = 7 instead of fifteen.
+#ifndef OFARN_HSUM3
+#define OFARN_HSUM3 1
+#endif
+
+// lane i <- src[lane i+1]; lane 63 (no source lane) keeps `edge`
+__device__ __forceinline__ double wave_shl1(double edge, double src)
+{
+    const int lo = __builtin_amdgcn_update_dpp((int)__double2loint(edge), (int)__double2loint(src), 0x130, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)__double2hiint(edge), (int)__double2hiint(src), 0x130, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 
 template <int M_, int MODE>   // MODE 0: flow_in == 0;  1: flow_in = upsample(coarse)*mul;  2: flow_in from HBM
 __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
@@ -211,6 +227,9 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
 #endif
     bool have_prev = false;                  // a row's column sums are in sV[buf ^ 1] awaiting their horizontal pass
     int yprev = 0;
+    constexpr bool H3 = OFARN_HSUM3 && (TAPS % 3 == 0);
+    __shared__ double sE[H3 ? 2 : 1][5][FI_THREADS / 64 + 1][2];   // first two column sums of every wave (edge buffer)
+    double Vp[5] = {0, 0, 0, 0, 0};          // H3: this thread's column sums of the previous row
     const int tc = clampi(tid, M_, FI_THREADS - M_ - 1);   // halo threads redo a neighbour's sums (no branch)
     const bool writer = tid >= M_ && tid < FI_THREADS - M_ && x < w;
     auto hsum_row = [&](const int b, const int y) {
@@ -226,9 +245,47 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
             __attribute__((address_space(3))) const double *v =
                 (__attribute__((address_space(3))) const double *)&sV[b][c][tc - M_];
             asm volatile("" : "+v"(v), "+v"(chain));
+            double s2 = 0;
+#pragma unroll
+            for (int i0 = 0; i0 < TAPS; i0 += 3) {   // chunks of three, left to right
+                double ch = v[i0];
+                if (i0 + 1 < TAPS) ch += v[i0 + 1];
+                if (i0 + 2 < TAPS) ch += v[i0 + 2];
+                s2 = i0 == 0 ? ch : s2 + ch;
+            }
+            g[c] = s2 * scale;
+            chain = s2;
+        }
+        const double idet = 1. / (g[0] * g[2] - g[1] * g[1] + 1e-3);
+        float2 o;
+        o.x = (float)((g[0] * g[4] - g[1] * g[3]) * idet);
+        o.y = (float)((g[2] * g[3] - g[1] * g[4]) * idet);
+        if (writer) stg_f2(fout, ((unsigned)y * (unsigned)w + (unsigned)x) * 8u, o);
+    };
+    // H3 stages.  tsum_row: chunk sums of the row whose column sums are in Vp (edges in sE[e]) -> sV[bt].
+    auto tsum_row = [&](const int e, const int bt) {
+        const int wv = tid >> 6;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const double e1 = sE[e][c][wv + 1][0], e2 = sE[e][c][wv + 1][1];   // uniform addresses: broadcast reads
+            const double a = Vp[c];
+            const double s1 = wave_shl1(e1, a);
+            const double s2 = wave_shl1(e2, s1);
+            sV[bt][c][tid] = (a + s1) + s2;
+        }
+    };
+    // hsum3_row: window sum of row y out of the chunk sums in sV[b], solve, store.
+    auto hsum3_row = [&](const int b, const int y) {
+        double g[5];
+        double chain = 0;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            __attribute__((address_space(3))) const double *v =
+                (__attribute__((address_space(3))) const double *)&sV[b][c][tc - M_];
+            asm volatile("" : "+v"(v), "+v"(chain));
             double s2 = v[0];
 #pragma unroll
-            for (int i = 1; i < TAPS; i++) s2 += v[i];
+            for (int i = 3; i < TAPS; i += 3) s2 += v[i];
             g[c] = s2 * scale;
             chain = s2;
         }
@@ -275,6 +332,32 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
         // exchanged one step ago) sits in the same straight-line code as this row's column sums, so
         // the scheduler can interleave the LDS reads and f64 add chains of one with the f32 math,
         // register-FIFO traffic and f64 updates of the other.  One barrier per step.
+        if constexpr (H3) {
+            // three rows in flight: window sums + solve of row t-B-1 (chunk sums written one step ago), chunk
+            // sums of row t-B (column sums in Vp, edges written one step ago), column sums of row t-(B-1)
+            const int par = step & 1;
+            if (step >= B + 1) hsum3_row(par ^ 1, t - B - 1);
+            if (step >= B) tsum_row(par ^ 1, par);
+            STAMP(5);
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const double vn = (double)m[c];
+                double V;
+                if constexpr (KIND == 0) P[c] = vn; else P[c] = P[c] + vn;
+                if constexpr (KIND == 2) { V = P[c]; S[c] = P[c]; }
+                else { S[c] = S[c] - (double)old[c]; V = S[c] + P[c]; }
+                Vp[c] = V;
+            }
+            if (emit && (tid & 63) < 2) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) sE[par][c][tid >> 6][tid & 63] = Vp[c];
+            }
+            STAMP(3);
+            if (!emit) return;
+            barrier_lds_only();
+            STAMP(4);
+            return;
+        }
         if (have_prev) hsum_row(buf ^ 1, yprev);
         STAMP(5);
 #pragma unroll
@@ -309,7 +392,16 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
                 step++;
             }
         }
-        if (have_prev) hsum_row(buf ^ 1, yprev);     // drain the pipeline: last output row
+        if constexpr (H3) {
+            // drain: chunk sums of the last row, then the two outstanding window sums
+            const int par = nsteps & 1;
+            if (nsteps >= B + 1) hsum3_row(par ^ 1, y0 + nsteps - B - 1);
+            if (nsteps >= B) {
+                tsum_row(par ^ 1, par);
+                barrier_lds_only();
+                hsum3_row(par, y0 + nsteps - B);
+            }
+        } else if (have_prev) hsum_row(buf ^ 1, yprev);     // drain the pipeline: last output row
     }
 #ifdef OFARN_STAMPS
     if (up.dbg && (tid & 63) == 0)

@@ -209,7 +209,8 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
 //            r' (row r'-m clamped) and aligned blocks of B rows,
 //              T_b = v[Bb] + ... + v[Bb+B-1] (left to right), S_b(j) = S_b(j-1) - v[Bb+j-1],
 //              colsum(Bb) = T_b,  colsum(Bb+j) = S_b(j) + P_{b+1}(j-1)
-//   rows:    sum_{i=-m..m} colsum[clamp(x+i)] left to right.
+//   rows:    the 2m+1 column sums colsum[clamp(x-m+i)] in chunks of three, left to right:
+//            ((e0+e1)+e2) + ((e3+e4)+e5) + ...
 // One block = TW columns x one aligned block-row of B output rows; one channel at a time:
 // phase A, one thread per column (with halo) marches the B outputs reading M straight from
 // HBM/L2 (coalesced across columns); phase B sums horizontally out of LDS.
@@ -250,8 +251,13 @@ __global__ __launch_bounds__(256) void k_blur_solve(const float *__restrict__ M,
             if (idx < nout) {
                 const int ly = idx / TW, ox = idx - ly * TW;
                 const double *rowv = sV + ly * IW + ox;
-                double s = rowv[0];
-                for (int i = 1; i <= 2 * m; i++) s += rowv[i];
+                double s = 0;
+                for (int i0 = 0; i0 < B; i0 += 3) {   // chunks of three, left to right (oracle OFO_BOX_BLOCKED)
+                    double ch = rowv[i0];
+                    if (i0 + 1 < B) ch += rowv[i0 + 1];
+                    if (i0 + 2 < B) ch += rowv[i0 + 2];
+                    s = i0 == 0 ? ch : s + ch;
+                }
                 acc[q][c] = s;
             }
         }

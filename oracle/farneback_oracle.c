@@ -452,8 +452,11 @@ static inline void ofo_solve(double g11, double g12, double g22, double h1, doub
  *       S_b(0) = T_b;  S_b(j) = S_b(j-1) - v[Bb+j-1]       (what is left of block b from offset j)
  *       colsum(y) = T_b                    if y = B*b
  *                 = S_b(j) + P_{b+1}(j-1)  if y = B*b + j, 0 < j < B
- *   The horizontal pass is the direct left-to-right sum of OFO_BOX_DIRECT.  This is the order the
- *   HIP kernels use, so device results can be compared bit for bit.
+ *   The horizontal pass adds the 2m+1 column sums in chunks of three, left to right:
+ *       window = ((e0+e1)+e2) + ((e3+e4)+e5) + ...   (a shorter last chunk if 3 does not divide 2m+1)
+ *   -- the fused kernel forms the chunk sums once per column with two whole-wave register shifts and
+ *   reads five of them per window instead of fifteen column sums.  This is the order the HIP kernels
+ *   use, so device results can be compared bit for bit.
  * OpenCV re-runs UpdateMatrices on row stripes as soon as the blur has passed them; a stripe is
  * only rewritten after its last reader, so that schedule equals the two-phase form used here. */
 OFO_API void ofo_update_flow_blur(const float *R0, const float *R1, float *flow_, float *M,
@@ -537,11 +540,25 @@ OFO_API void ofo_update_flow_blur(const float *R0, const float *R1, float *flow_
             }
             for (int x = 0; x < width; x++) {
                 double s[5];
-                int xl = x - m < 0 ? 0 : x - m;
-                for (int c = 0; c < 5; c++) s[c] = vsum[xl * 5 + c];
-                for (int i = -m + 1; i <= m; i++) {
-                    int xx = x + i; if (xx < 0) xx = 0; if (xx > width - 1) xx = width - 1;
-                    for (int c = 0; c < 5; c++) s[c] += vsum[xx * 5 + c];
+                if (box_mode == OFO_BOX_BLOCKED) {
+                    /* chunks of three columns, left to right: ((e0+e1)+e2) + ((e3+e4)+e5) + ... */
+                    for (int c = 0; c < 5; c++) {
+                        for (int i0 = 0; i0 < B; i0 += 3) {
+                            double ch = 0;
+                            for (int i = i0; i < i0 + 3 && i < B; i++) {
+                                int xx = x - m + i; if (xx < 0) xx = 0; if (xx > width - 1) xx = width - 1;
+                                ch = i == i0 ? vsum[xx * 5 + c] : ch + vsum[xx * 5 + c];
+                            }
+                            s[c] = i0 == 0 ? ch : s[c] + ch;
+                        }
+                    }
+                } else {
+                    int xl = x - m < 0 ? 0 : x - m;
+                    for (int c = 0; c < 5; c++) s[c] = vsum[xl * 5 + c];
+                    for (int i = -m + 1; i <= m; i++) {
+                        int xx = x + i; if (xx < 0) xx = 0; if (xx > width - 1) xx = width - 1;
+                        for (int c = 0; c < 5; c++) s[c] += vsum[xx * 5 + c];
+                    }
                 }
                 ofo_solve(s[0], s[1], s[2], s[3], s[4], scale, flow + x * 2);
             }
