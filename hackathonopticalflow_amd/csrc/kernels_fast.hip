@@ -622,8 +622,158 @@ __global__ __launch_bounds__(256) void k_level_hpass_multi(const uint8_t *__rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_level_direct<S, K>: the whole of stage A for one level whose size is EXACTLY 1/S of the frame in both
+// directions (S = 2, 4, 8 with pyr_scale 0.5 and sizes divisible by S): uint8 frame in, level image out,
+// nothing in between goes to HBM.  Same arithmetic, in the same order, as row pass + column pass + resize:
+//   row pass    t[v][c]  = k[0]*f[c-r] + k[1]*f[c-r+1] + ...                     (left to right, reflect-101)
+//   column pass b[row]   = k[r]*t[row] + sum_i k[r+i]*(t[row+i] + t[row-i])      (i = 1..r)
+//   resize      out      = (b00*a0 + b01*a1)*w0 + (b10*a0 + b11*a1)*w1,  a = w = 1/2 here
+// A level pixel (x, y) samples source columns c0 = S*x + S/2 - 1, c0 + 1 and source rows sy = S*y + S/2 - 1,
+// sy + 1.  One thread per level column marches down a strip of level rows; the row-pass results of the last
+// 3*S source rows live in a register ring (K + 1 <= 3*S rows are needed per output) that is addressed
+// statically because the marching loop is unrolled by the ring period of three output rows; each output
+// row costs S new row passes (K + 1 byte loads each).
+// ---------------------------------------------------------------------------------------------
+template <int K> struct TapsArg { float k[K]; };
+
+__device__ __forceinline__ int reflect101_once(int p, int len)   // valid for -len < p < 2*len - 1
+{
+    p = p < 0 ? -p : p;
+    return p >= len ? 2 * len - 2 - p : p;
+}
+
+// EDGE = false: level columns 1 .. w-2, whose K+1 source bytes lie inside the row: they are fetched as aligned
+//               dwords (the window start S*x + S/2 - 1 - r has the same alignment for every x when S >= 4) and
+//               unpacked with v_cvt_f32_ubyteN.
+// EDGE = true : level columns 0 and w-1 (the only ones whose taps cross the left / right border for these
+//               (S, K)), byte loads at reflect-101 indices; thread = (strip, column), a tiny second launch.
+template <int S, int K, bool EDGE>
+__global__ __launch_bounds__(EDGE ? 64 : 256) void k_level_direct(const uint8_t *__restrict__ frames, size_t frame_stride,
+                                                                  int W, int H, TapsArg<K> taps, float *__restrict__ I, int w,
+                                                                  int h, int strip)
+{
+    constexpr int R = 3 * S, r = K / 2;
+    static_assert(K + 1 <= R && (K & 1), "ring of 3*S rows must hold the K+1 rows of one output");
+    int x, dy0;
+    if (EDGE) {
+        const int sidx = blockIdx.y * 32 + (threadIdx.x >> 1);
+        x = (threadIdx.x & 1) ? w - 1 : 0;
+        dy0 = sidx * strip;
+        if (dy0 >= h || (w == 1 && (threadIdx.x & 1))) return;
+    } else {
+        x = 1 + blockIdx.x * 256 + threadIdx.x;
+        dy0 = blockIdx.y * strip;
+        if (x > w - 2) return;
+    }
+    const int dy1 = min(dy0 + strip, h);
+    const uint8_t *f = frames + (size_t)blockIdx.z * frame_stride;
+    float *out = I + (size_t)blockIdx.z * w * h;
+    const int cl = S * x + S / 2 - 1 - r;            // source column of tap 0 of the left sampled column
+    float ring[R][2];
+
+    // row pass of virtual source row v (reflected into the frame) at the two sampled columns
+    auto rowpass = [&](int v, float &o0, float &o1) {
+        const uint8_t *row = f + (size_t)reflect101_once(v, H) * W;
+        float px[K + 1];
+        if (EDGE) {
+#pragma unroll
+            for (int t = 0; t <= K; t++) px[t] = (float)row[reflect101_once(cl + t, W)];
+        } else if (S >= 4) {
+            constexpr int OFF = (((S / 2 - 1 - r) % 4) + 4) % 4;     // cl - (cl rounded down to a multiple of 4)
+            constexpr int ND = (OFF + K + 1 + 3) / 4;
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(row + (cl - OFF));
+            uint32_t d[ND];
+#pragma unroll
+            for (int i = 0; i < ND; i++) d[i] = q[i];
+#pragma unroll
+            for (int t = 0; t <= K; t++) px[t] = (float)((d[(OFF + t) / 4] >> (8 * ((OFF + t) % 4))) & 255u);
+        } else {
+#pragma unroll
+            for (int t = 0; t <= K; t++) px[t] = (float)row[cl + t];
+        }
+        float a0 = taps.k[0] * px[0], a1 = taps.k[0] * px[1];
+#pragma unroll
+        for (int t = 1; t < K; t++) {
+            a0 = a0 + taps.k[t] * px[t];
+            a1 = a1 + taps.k[t] * px[t + 1];
+        }
+        o0 = a0;
+        o1 = a1;
+    };
+    const int vbase = S * dy0 + S / 2 - 1 - r;       // virtual source row of ring slot 0
+    // warm-up: the K+1-S rows the first output needs beyond its own S new ones
+#pragma unroll
+    for (int j = 0; j < K + 1 - S; j++) rowpass(vbase + j, ring[j % R][0], ring[j % R][1]);
+
+    for (int dy = dy0; dy < dy1; dy += 3) {
+        const int vg = vbase + S * (dy - dy0);       // virtual row of slot 0 for this group of three outputs
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            if (dy + b < dy1) {
+#pragma unroll
+                for (int jj = 0; jj < S; jj++) {
+                    const int j = K + 1 - S + jj;
+                    rowpass(vg + S * b + j, ring[(S * b + j) % R][0], ring[(S * b + j) % R][1]);
+                }
+                float bb[2][2];
+#pragma unroll
+                for (int q = 0; q < 2; q++)          // sampled rows sy (q = 0) and sy + 1 (q = 1)
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        float acc = taps.k[r] * ring[(S * b + r + q) % R][c];
+#pragma unroll
+                        for (int i = 1; i <= r; i++)
+                            acc = acc + taps.k[r + i] * (ring[(S * b + r + q + i) % R][c] + ring[(S * b + r + q - i) % R][c]);
+                        bb[q][c] = acc;
+                    }
+                const float row0 = bb[0][0] * 0.5f + bb[0][1] * 0.5f;
+                const float row1 = bb[1][0] * 0.5f + bb[1][1] * 0.5f;
+                out[(size_t)(dy + b) * w + x] = row0 * 0.5f + row1 * 0.5f;
+            }
+        }
+    }
+}
+
 static inline unsigned cdivu(int a, int b) { return (unsigned)((a + b - 1) / b); }
 int best_strip_units(int nunits, int unit, int warm, int blocks_per_strip_row, int blocks_per_cu);
+
+// Direct level build: supported when the level is exactly 1/S of the frame (S = 2, 4, 8), the kernel has the
+// size getGaussianKernel gives for that scale (3, 9, 19 taps) and the frames are aligned for dword loads.
+bool level_direct_supported(const void *frames, int W, int H, int w, int h, int ksize)
+{
+    if (w < 2 || h < 1 || ((uintptr_t)frames & 7)) return false;
+    return (W == 2 * w && H == 2 * h && ksize == 3) || (W == 4 * w && H == 4 * h && ksize == 9) ||
+           (W == 8 * w && H == 8 * h && ksize == 19);
+}
+
+template <int S, int K>
+static void launch_level_direct_sk(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
+                                   const float *h_kern, float *I, int w, int h)
+{
+    TapsArg<K> taps;
+    for (int i = 0; i < K; i++) taps.k[i] = h_kern[i];
+    // strips of a multiple of three level rows; each strip re-does K+1-S row passes of warm-up
+    const int units = (h + 2) / 3;
+    if (w > 2) {
+        const int strip = 3 * best_strip_units(units, 3 * S, K + 1 - S, (int)cdivu(w - 2, 256) * nframes, 8);
+        dim3 grid(cdivu(w - 2, 256), cdivu(h, strip), nframes);
+        hipLaunchKernelGGL((k_level_direct<S, K, false>), grid, dim3(256), 0, s, frames, frame_stride, W, H, taps, I, w, h, strip);
+    }
+    // border columns 0 and w-1: 32 strips of at least 12 rows per block of 64 threads
+    int estrip = 3 * ((units + 31) / 32);
+    if (estrip < 12) estrip = 12;
+    dim3 egrid(1, cdivu((int)cdivu(h, estrip), 32), nframes);
+    hipLaunchKernelGGL((k_level_direct<S, K, true>), egrid, dim3(64), 0, s, frames, frame_stride, W, H, taps, I, w, h, estrip);
+}
+
+void launch_level_direct(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
+                         const float *h_kern, int ksize, float *I, int w, int h)
+{
+    if (W == 2 * w && ksize == 3) launch_level_direct_sk<2, 3>(s, frames, frame_stride, W, H, nframes, h_kern, I, w, h);
+    else if (W == 4 * w && ksize == 9) launch_level_direct_sk<4, 9>(s, frames, frame_stride, W, H, nframes, h_kern, I, w, h);
+    else if (W == 8 * w && ksize == 19) launch_level_direct_sk<8, 19>(s, frames, frame_stride, W, H, nframes, h_kern, I, w, h);
+}
 
 // The fused kernel is instantiated for these window half-widths m = winsize/2 (winsize 7..21 and
 // the even sizes sharing an m); other window sizes take the generic unfused kernels.

@@ -170,6 +170,7 @@ struct Level {
     // device tables
     float *d_kern = nullptr;
     float h_kern3[3] = {0, 0, 0};   // host copy of the taps when ksize == 3
+    std::vector<float> h_kern;      // host copy of all taps (passed by value to k_level_direct)
     int *d_xofs = nullptr, *d_yofs = nullptr;        // image resize W->w, H->h
     float *d_xa = nullptr, *d_ya = nullptr;
     int *d_fxofs = nullptr, *d_fyofs = nullptr;      // flow resize (k+1) -> k
@@ -335,6 +336,7 @@ int make_plan(ofarn_ctx *c, int w, int h)
         {
             const std::vector<float> kv = gaussian_kernel(L.ksize, L.sigma);
             if (L.ksize == 3) for (int i = 0; i < 3; i++) L.h_kern3[i] = kv[i];
+            L.h_kern = kv;
             if ((rc = upload(c, kv, &L.d_kern))) return rc;
         }
         std::vector<int> ofs;
@@ -426,6 +428,7 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
         for (int k = nlev; k >= 0 && ok; k--) {
             const Level &L = c->lv[k];
             if (march0 && L.w == w && L.h == h && L.ksize == 3) continue;   // fused into the poly expansion
+            if (level_direct_supported(d_frames, w, h, L.w, L.h, L.ksize)) continue;   // built by k_level_direct, no tmp
             const size_t need = (size_t)nframes * h * L.w * 2;
             if (HL.n >= 12 || off + need > c->tmp_floats) { ok = false; break; }
             HL.lv[HL.n++] = HLevel{L.d_kern, L.d_xofs, ws.tmp + off, L.w, L.ksize};
@@ -464,6 +467,15 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
             // scale 1: 3-tap blur fused into the polynomial expansion, frames read directly
             timed(c, s, OFARN_STAGE_POLYEXP, k, ufr, [&] {
                 launch_polyexp_march(s, d_frames, fsz, 1, ws.R, L.w, L.h, nframes, c->poly, L.h_kern3);
+            });
+        } else if (!c->force_generic && level_direct_supported(d_frames, w, h, L.w, L.h, L.ksize)) {
+            // exact 1/2, 1/4, 1/8 levels: row pass + column pass + resize in one kernel straight from the frames
+            timed(c, s, OFARN_STAGE_LEVEL_V, k, ufr, [&] {
+                launch_level_direct(s, d_frames, fsz, w, h, nframes, L.h_kern.data(), L.ksize, ws.I, L.w, L.h);
+            });
+            timed(c, s, OFARN_STAGE_POLYEXP, k, ufr, [&] {
+                if (march) launch_polyexp_march(s, ws.I, npx, 0, ws.R, L.w, L.h, nframes, c->poly, L.h_kern3);
+                else launch_polyexp(s, ws.I, ws.R, L.w, L.h, nframes, c->poly);
             });
         } else {
             float *tmpk = tmp_of[k] ? tmp_of[k] : ws.tmp;
@@ -1189,11 +1201,15 @@ int ofarn_stage_level_image(ofarn_ctx *c, const uint8_t *h_img, int w, int h, in
     if ((rc = ensure_staging(c, fsz, 0, 0))) return rc;
     HIP_TRY(hipMemcpyAsync(c->st_frames, h_img, fsz, hipMemcpyHostToDevice, c->stream));
     const bool lds_ok = (size_t)(w + 2 * (L.ksize / 2)) * 4 * 33 / 32 + 4 * (size_t)L.ksize + 64 <= 60 * 1024;
-    if (!c->force_generic && lds_ok)
-        launch_level_hpass_lds(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->ws[0].tmp);
-    else
-        launch_level_hpass(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->ws[0].tmp);
-    launch_level_vpass(c->stream, c->ws[0].tmp, h, L.w, L.h, 1, L.d_kern, L.ksize, L.d_xa, L.d_yofs, L.d_ya, c->ws[0].I);
+    if (!c->force_generic && level_direct_supported(c->st_frames, w, h, L.w, L.h, L.ksize))
+        launch_level_direct(c->stream, c->st_frames, fsz, w, h, 1, L.h_kern.data(), L.ksize, c->ws[0].I, L.w, L.h);
+    else {
+        if (!c->force_generic && lds_ok)
+            launch_level_hpass_lds(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->ws[0].tmp);
+        else
+            launch_level_hpass(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->ws[0].tmp);
+        launch_level_vpass(c->stream, c->ws[0].tmp, h, L.w, L.h, 1, L.d_kern, L.ksize, L.d_xa, L.d_yofs, L.d_ya, c->ws[0].I);
+    }
     HIP_TRY(hipMemcpyAsync(h_out, c->ws[0].I, (size_t)L.w * L.h * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return OFARN_OK;

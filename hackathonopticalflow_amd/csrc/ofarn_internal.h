@@ -85,6 +85,11 @@ struct HLevels {
 size_t hpass_multi_lds_bytes(int W, int rmax);
 void launch_level_hpass_multi(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
                               const HLevels &L);
+// Stage A in one kernel, no intermediate in HBM, for levels that are exactly 1/2, 1/4 or 1/8 of the frame
+// (kernels_fast.hip).  h_kern: host pointer to the ksize taps.
+bool level_direct_supported(const void *frames, int W, int H, int w, int h, int ksize);
+void launch_level_direct(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
+                         const float *h_kern, int ksize, float *I, int w, int h);
 // Stage F: grid sample + vector filter + danger brightness.  d_pts int2[P] grid coordinates.
 int grid_filter_lds_bytes(int P);
 void launch_grid_filter(hipStream_t s, const float *flow, int w, int h, int npairs, const int *d_pts,
