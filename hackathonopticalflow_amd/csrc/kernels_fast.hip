@@ -563,13 +563,27 @@ __global__ __launch_bounds__(256) void k_level_hpass_multi(const uint8_t *__rest
     const int y = blockIdx.y;
     const uint8_t *row = frames + (size_t)blockIdx.z * frame_stride + (size_t)y * W;
     const int tid = threadIdx.x;
+    const int NT = blockDim.x;
     const int rmax = L.rmax, ext = W + 2 * rmax;
     float *sk = srow + skew(ext) + 1;        // all levels' kernel taps, back to back
-    for (int i = tid; i < ext; i += 256) srow[skew(i)] = (float)row[reflect101(i - rmax, W)];
+    if ((rmax & 3) == 0 && (W & 3) == 0 && ((uintptr_t)row & 3) == 0) {
+        // interior four pixels at a time: one dword load, four v_cvt_f32_ubyteN, one 16-byte LDS write (the border
+        // width is a multiple of 4, so a group never straddles a skew step); the two borders element by element
+        for (int c = 4 * tid; c < W; c += 4 * NT) {
+            const uint32_t d = *reinterpret_cast<const uint32_t *>(row + c);
+            *reinterpret_cast<float4 *>(&srow[skew(c + rmax)]) =
+                make_float4((float)(d & 255u), (float)((d >> 8) & 255u), (float)((d >> 16) & 255u), (float)(d >> 24));
+        }
+        for (int i = tid; i < 2 * rmax; i += NT) {
+            const int e = i < rmax ? i : W + i;          // extended index: left border, then right border
+            srow[skew(e)] = (float)row[reflect101(e - rmax, W)];
+        }
+    } else
+        for (int i = tid; i < ext; i += NT) srow[skew(i)] = (float)row[reflect101(i - rmax, W)];
     {
         int off = 0;
         for (int l = 0; l < L.n; l++) {
-            for (int i = tid; i < L.lv[l].ksize; i += 256) sk[off + i] = L.lv[l].kern[i];
+            for (int i = tid; i < L.lv[l].ksize; i += NT) sk[off + i] = L.lv[l].kern[i];
             off += L.lv[l].ksize;
         }
     }
@@ -581,7 +595,7 @@ __global__ __launch_bounds__(256) void k_level_hpass_multi(const uint8_t *__rest
         const float *kk = sk + koff;
         koff += lv.ksize;
         float2 *dst = reinterpret_cast<float2 *>(lv.dst) + ((size_t)blockIdx.z * H + y) * lv.dw;
-        for (int dx = tid; dx < lv.dw; dx += 256) {
+        for (int dx = tid; dx < lv.dw; dx += NT) {
             const int sx = lv.xofs[dx];
             const int p = sx - r + rmax;             // extended index of tap 0 of the left column
             float acc0, acc1;
@@ -912,7 +926,13 @@ void launch_level_hpass_multi(hipStream_t s, const uint8_t *frames, size_t frame
                               const HLevels &L)
 {
     dim3 grid(1, H, nframes);
-    hipLaunchKernelGGL(k_level_hpass_multi, grid, dim3(256), hpass_multi_lds_bytes(W, L.rmax), s, frames, frame_stride,
+#ifndef OFARN_HP_THREADS
+#define OFARN_HP_THREADS 256
+#endif
+    int maxdw = 0;
+    for (int i = 0; i < L.n; i++) maxdw = L.lv[i].dw > maxdw ? L.lv[i].dw : maxdw;
+    const int nt = maxdw <= 128 ? OFARN_HP_THREADS : 256;   // few columns: smaller blocks leave no idle waves
+    hipLaunchKernelGGL(k_level_hpass_multi, grid, dim3(nt), hpass_multi_lds_bytes(W, L.rmax), s, frames, frame_stride,
                        W, H, L);
 }
 

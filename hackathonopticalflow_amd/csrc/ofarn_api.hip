@@ -436,6 +436,7 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
             tmp_of[k] = ws.tmp + off;
             off += need;
         }
+        HL.rmax = (HL.rmax + 3) & ~3;   // border width in LDS: a multiple of 4 keeps the 16-byte staging writes aligned
         if (ok && HL.n > 0 && hpass_multi_lds_bytes(w, HL.rmax) <= 60 * 1024) {
             double units = 0;
             for (int i = 0; i < HL.n; i++) units += (double)HL.lv[i].dw * h * nframes;
