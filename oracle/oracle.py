@@ -43,7 +43,7 @@ class OfoCapture(C.Structure):
 def build(force: bool = False) -> None:
     """Compile the oracle with gcc (oracle/Makefile)."""
     so = os.path.join(_BUILD, "libofarn_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("farneback_oracle.c", "filter_oracle.c", "frontend_oracle.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("farneback_oracle.c", "filter_oracle.c", "frontend_oracle.c", "lk_oracle.c", "Makefile")]
     if (not force and os.path.exists(so)
             and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs)
             and os.path.exists(os.path.join(_BUILD, "libofarn_oracle_omp.so"))):
@@ -107,6 +107,15 @@ def lib(omp: bool = False) -> C.CDLL:
         l.ofo_resize_area.restype = C.c_int
         l.ofo_hsv2bgr_u8.argtypes = [u8p, C.c_size_t, u8p]
         l.ofo_hsv2bgr_u8.restype = None
+        l.ofo_pyrdown_u8.argtypes = [u8p, C.c_int, C.c_int, u8p]
+        l.ofo_pyrdown_u8.restype = None
+        l.ofo_scharr_deriv.argtypes = [u8p, C.c_int, C.c_int, C.POINTER(C.c_int16)]
+        l.ofo_scharr_deriv.restype = None
+        l.ofo_lk_levels.argtypes = [C.c_int] * 5
+        l.ofo_lk_levels.restype = C.c_int
+        l.ofo_pyr_lk.argtypes = [u8p, u8p, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                 C.c_int, C.c_double, C.c_int, fp, u8p, fp]
+        l.ofo_pyr_lk.restype = C.c_int
         _libs[omp] = l
     return _libs[omp]
 
@@ -444,3 +453,63 @@ def draw_flow_lines_numpy(img_shape, flow, step=14):
     lines = np.vstack([x, y, x - fx, y - fy]).T.reshape(-1, 2, 2)
     lines = np.int32(lines + 0.5)
     return lines
+
+
+# --------------------------------------------------------------------------- sparse pyramidal Lucas-Kanade
+LK_SUM_SCALAR = 0    # row-major float accumulation: lkpyramid.cpp's scalar loop
+LK_SUM_COLUMNS = 1   # per window column, then the columns left to right: the HIP kernel's order
+LK_GET_MIN_EIGENVALS = 8
+LK_USE_INITIAL_FLOW = 4
+
+
+def pyrdown_u8(img):
+    """cv2.pyrDown on uint8[H,W] (BORDER_REFLECT_101, as buildOpticalFlowPyramid calls it)."""
+    a = np.ascontiguousarray(img, np.uint8)
+    h, w = a.shape
+    out = np.empty(((h + 1) // 2, (w + 1) // 2), np.uint8)
+    lib().ofo_pyrdown_u8(_u8p(a), w, h, _u8p(out))
+    return out
+
+
+def scharr_deriv(img):
+    """calcScharrDeriv: int16[H,W,2] = (dI/dx, dI/dy), unscaled 3-10-3 Scharr."""
+    a = np.ascontiguousarray(img, np.uint8)
+    h, w = a.shape
+    out = np.empty((h, w, 2), np.int16)
+    lib().ofo_scharr_deriv(_u8p(a), w, h, out.ctypes.data_as(C.POINTER(C.c_int16)))
+    return out
+
+
+def lk_levels(w, h, win, max_level):
+    return lib().ofo_lk_levels(w, h, win[0], win[1], max_level)
+
+
+def calc_optical_flow_pyr_lk(prev, next, pts, next_pts=None, winSize=(21, 21), maxLevel=3, criteria=(30, 0.01), flags=0,
+                             minEigThreshold=1e-4, sum_mode=LK_SUM_SCALAR):
+    """cv2.calcOpticalFlowPyrLK(prev, next, pts, next_pts, winSize=, maxLevel=, criteria=(COUNT|EPS, count, eps), flags=,
+    minEigThreshold=) -> (next_pts float32[n,2], status uint8[n], err float32[n]); criteria here = (count, eps)."""
+    prev = np.ascontiguousarray(prev, np.uint8)
+    next = np.ascontiguousarray(next, np.uint8)
+    pts = np.ascontiguousarray(np.asarray(pts, np.float32).reshape(-1, 2))
+    n = len(pts)
+    out = np.zeros((n, 2), np.float32) if next_pts is None else np.array(np.asarray(next_pts, np.float32).reshape(-1, 2), order="C")
+    status = np.zeros(n, np.uint8)
+    err = np.zeros(n, np.float32)
+    h, w = prev.shape
+    rc = lib().ofo_pyr_lk(_u8p(prev), _u8p(next), w, h, _fp(pts), n, winSize[0], winSize[1], maxLevel, criteria[0],
+                          criteria[1], flags, minEigThreshold, sum_mode, _fp(out), _u8p(status), _fp(err))
+    if rc:
+        raise ValueError(f"oracle pyr_lk rejected arguments (rc={rc})")
+    return out, status, err
+
+
+def get_flow_lk_numpy(img1, img2, points_, width, height, sum_mode=LK_SUM_SCALAR, next_pts=None):
+    """pathfinder_viewer.py:144-178 (get_flow_lk) without the drawing: LK from img2 to img1 at the grid points, then
+    the vector filter.  Returns (mask bool[P], flow int32[P,2] for all points, ipoints int32[P,2], next_pts float32[P,2]).
+    next_pts: use these tracked points instead of running the oracle LK (to compare filters on identical vectors)."""
+    if next_pts is None:
+        next_pts, _status, _err = calc_optical_flow_pyr_lk(img2, img1, points_, None, winSize=(45, 45), maxLevel=2,
+                                                            criteria=(10, 0.03), sum_mode=sum_mode)
+    flow_ = next_pts - points_
+    mask, _mod, iflow, ipts = vector_filter_numpy(flow_, points_, width, height, 0)
+    return mask, iflow, ipts, next_pts
