@@ -355,24 +355,26 @@ __device__ __forceinline__ int next_pow2(int v) { int p = 1; while (p < v) p <<=
 __global__ __launch_bounds__(1024) void k_grid_filter(const float2 *__restrict__ flow, int w, int h,
                                                        const int2 *__restrict__ pts, int P, int P2, int variant,
                                                        uint8_t *__restrict__ mask, uint8_t *__restrict__ v,
-                                                       int *__restrict__ iflow)
+                                                       int *__restrict__ iflow, const float2 *__restrict__ vecs)
 {
     extern __shared__ float smem[];
     float *srt = smem;          // [P2]
     __shared__ float s_thr[2];
     const int tid = threadIdx.x, nt = blockDim.x;
-    const float2 *f = flow + (size_t)blockIdx.x * w * h;
+    // vectors at the grid points: sampled from the dense flow (DenseOF.py:44-45), or given (LK: next_pts - points_)
+    const float2 *f = flow ? flow + (size_t)blockIdx.x * w * h : nullptr;
+    const float2 *vp = vecs ? vecs + (size_t)blockIdx.x * P : nullptr;
     const float hw = (float)(w / 2), hh = (float)(h / 2);
 
     for (int i = tid; i < P2; i += nt) {
         float mval = __builtin_inff();
         if (i < P) {
             const int2 p = pts[i];
-            const float2 d = f[(size_t)p.y * w + p.x];
-            const float mod = __fsqrt_rn(d.x * d.x + d.y * d.y);
+            const float2 d = vp ? vp[i] : f[(size_t)p.y * w + p.x];
+            const float mod = sqrtf(d.x * d.x + d.y * d.y);
             const float ddx = hw - (float)p.x, ddy = hh - (float)p.y;
-            const float mm = __fsqrt_rn(ddx * ddx + ddy * ddy);
-            mval = __fdiv_rn(mod, 5.0f + __fsqrt_rn(mm)) * 30.0f;
+            const float mm = sqrtf(ddx * ddx + ddy * ddy);
+            mval = __fdiv_rn(mod, 5.0f + sqrtf(mm)) * 30.0f;
         }
         srt[i] = mval;
     }
@@ -411,12 +413,12 @@ __global__ __launch_bounds__(1024) void k_grid_filter(const float2 *__restrict__
     const float med = s_thr[0], p99 = s_thr[1];
     for (int i = tid; i < P; i += nt) {
         const int2 p = pts[i];
-        const float2 d = f[(size_t)p.y * w + p.x];
+        const float2 d = vp ? vp[i] : f[(size_t)p.y * w + p.x];
         const float x = (float)p.x, y = (float)p.y;
-        const float mod0 = __fsqrt_rn(d.x * d.x + d.y * d.y);
+        const float mod0 = sqrtf(d.x * d.x + d.y * d.y);
         const float ddx = hw - x, ddy = hh - y;
-        const float mm = __fsqrt_rn(ddx * ddx + ddy * ddy);
-        const float mod = __fdiv_rn(mod0, 5.0f + __fsqrt_rn(mm)) * 30.0f;
+        const float mm = sqrtf(ddx * ddx + ddy * ddy);
+        const float mod = __fdiv_rn(mod0, 5.0f + sqrtf(mm)) * 30.0f;
         // variant 0: pathfinder_viewer.py:173  (median*1.0 < mod) & (mod < P99)
         // variant 1: DenseOF.py:228            mod > median*1.2   (float32 product)
         const bool keep = variant == 1 ? (mod > med * 1.2f) : ((med < mod) && (mod < p99));
@@ -532,13 +534,13 @@ int grid_filter_lds_bytes(int P)
 }
 
 void launch_grid_filter(hipStream_t s, const float *flow, int w, int h, int npairs, const int *d_pts, int P,
-                        int variant, uint8_t *mask, uint8_t *v, int32_t *iflow)
+                        int variant, uint8_t *mask, uint8_t *v, int32_t *iflow, const float *vecs)
 {
     int p2 = 1;
     while (p2 < P) p2 <<= 1;
     hipLaunchKernelGGL(k_grid_filter, dim3(npairs), dim3(1024), (size_t)p2 * sizeof(float), s,
                        reinterpret_cast<const float2 *>(flow), w, h, reinterpret_cast<const int2 *>(d_pts), P,
-                       p2, variant, mask, v, iflow);
+                       p2, variant, mask, v, iflow, reinterpret_cast<const float2 *>(vecs));
 }
 
 }  // namespace ofarn

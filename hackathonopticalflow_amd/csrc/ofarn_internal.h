@@ -93,7 +93,7 @@ void launch_level_direct(hipStream_t s, const uint8_t *frames, size_t frame_stri
 // Stage F: grid sample + vector filter + danger brightness.  d_pts int2[P] grid coordinates.
 int grid_filter_lds_bytes(int P);
 void launch_grid_filter(hipStream_t s, const float *flow, int w, int h, int npairs, const int *d_pts,
-                        int P, int variant, uint8_t *mask, uint8_t *v, int32_t *iflow);
+                        int P, int variant, uint8_t *mask, uint8_t *v, int32_t *iflow, const float *vecs = nullptr);
 
 // ---- front end / back end of the call (kernels_frontend.hip) ----
 // cv2.cvtColor(COLOR_BGR2GRAY) on n pixels of packed BGR; coefficients and shift from color_rgb.simd.hpp.
@@ -112,5 +112,24 @@ void launch_hsv2bgr(hipStream_t s, const uint8_t *hsv, size_t npx, uint8_t *bgr)
 // draw_flow: int32 [npairs][ny*nx][2][2] line end points
 void launch_flow_arrows(hipStream_t s, const float *flow, int w, int h, int npairs, int nx, int ny, double start, double step,
                         int32_t *lines);
+
+// ---- sparse pyramidal Lucas-Kanade (kernels_lk.hip) ----
+void launch_pyrdown_u8(hipStream_t s, const uint8_t *src, int sw, int sh, uint8_t *dst, int nframes);
+void launch_scharr(hipStream_t s, const uint8_t *src, int w, int h, int16_t *dst, int nframes);
+struct LkLevelArgs {
+    const uint8_t *img;      // this level's images of the wave: uint8 [F][h][w]
+    const int16_t *deriv;    // Scharr derivatives: int16 [F][h][w][2]
+    const float *pts;        // float2 points: [npts] shared by all pairs (pts_stride 0) or [pairs][npts] (pts_stride npts)
+    float *next_pts;         // float2 [pairs][npts], in/out across levels
+    uint8_t *status;         // [pairs][npts]
+    float *err;              // [pairs][npts]
+    int w, h, npts, pts_stride;
+    int fstep, i_off, j_off; // pair p tracks from frame p*fstep + i_off to frame p*fstep + j_off
+    int win_w, win_h, level, top_level, flags, max_count;
+    float scale, min_eig;    // (float)(1. / (1 << level)), (float)minEigThreshold
+    double eps2;             // epsilon^2
+};
+size_t lk_track_lds_bytes(int win_w, int win_h);
+void launch_lk_track(hipStream_t s, const LkLevelArgs &A, int npairs);
 
 }  // namespace ofarn

@@ -46,6 +46,16 @@ class OfarnParams(C.Structure):
                 ("flags", C.c_int), ("grid_step", C.c_int), ("filter_variant", C.c_int)]
 
 
+class OfarnLkParams(C.Structure):
+    """struct ofarn_lk_params (include/ofarn.h): the keyword arguments of cv2.calcOpticalFlowPyrLK."""
+    _fields_ = [("win_w", C.c_int), ("win_h", C.c_int), ("max_level", C.c_int), ("max_count", C.c_int),
+                ("epsilon", C.c_double), ("flags", C.c_int), ("min_eig_threshold", C.c_double)]
+
+
+OPTFLOW_LK_GET_MIN_EIGENVALS = 8
+TERM_CRITERIA_COUNT = 1   # cv2.TERM_CRITERIA_COUNT / MAX_ITER
+TERM_CRITERIA_EPS = 2     # cv2.TERM_CRITERIA_EPS
+
 _lib = None
 _lib_lock = threading.Lock()
 
@@ -80,6 +90,18 @@ ABI = {
     "ofarn_stage_blur_solve": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, _fp]),
     "ofarn_stage_flow_upsample": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ofarn_stage_resize_area": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
+    "ofarn_stage_pyrdown": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, _u8p]),
+    "ofarn_stage_scharr": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, C.POINTER(C.c_int16)]),
+    "ofarn_lk_default_params": (None, [C.POINTER(OfarnLkParams)]),
+    "ofarn_lk_levels": (C.c_int, [C.POINTER(OfarnLkParams), C.c_int, C.c_int]),
+    "ofarn_lk_calc": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.POINTER(OfarnLkParams),
+                                _fp, _u8p, _fp]),
+    "ofarn_lk_calc_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_int, C.c_int, C.POINTER(OfarnLkParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p]),
+    "ofarn_vector_filter": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, _u8p, _u8p, C.POINTER(C.c_int32)]),
+    "ofarn_vector_filter_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
     "ofarn_bgr2gray": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p]),
     "ofarn_bgr2gray_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ofarn_calc_batch_device_bgr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -161,6 +183,19 @@ def make_params(pyr_scale=0.5, levels=3, winsize=15, iterations=3, poly_n=5, pol
                 grid_step=30, filter_variant=0) -> OfarnParams:
     return OfarnParams(float(pyr_scale), int(levels), int(winsize), int(iterations), int(poly_n),
                        float(poly_sigma), int(flags), int(grid_step), int(filter_variant))
+
+
+def make_lk_params(winSize=(21, 21), maxLevel=3, criteria=(TERM_CRITERIA_COUNT | TERM_CRITERIA_EPS, 30, 0.01), flags=0,
+                   minEigThreshold=1e-4) -> OfarnLkParams:
+    """cv2.calcOpticalFlowPyrLK keyword arguments -> struct.  criteria = (type, maxCount, epsilon) as in cv2: a missing
+    COUNT bit means 30 iterations, a missing EPS bit means 0.01 (lkpyramid.cpp)."""
+    ctype, count, eps = criteria
+    if not (int(ctype) & TERM_CRITERIA_COUNT):
+        count = 30
+    if not (int(ctype) & TERM_CRITERIA_EPS):
+        eps = 0.01
+    return OfarnLkParams(int(winSize[0]), int(winSize[1]), int(maxLevel), int(count), float(eps), int(flags),
+                         float(minEigThreshold))
 
 
 def level_plan(width, height, **kw):
@@ -334,6 +369,78 @@ class FarnebackEngine:
     def flow_arrows_device(self, d_flow, n, width, height, step, d_lines, stream=None):
         _check(self._lib.ofarn_flow_arrows_device(self._h, _ptr(d_flow), n, width, height, step, _ptr(d_lines),
                                                   C.c_void_p(stream) if stream else None))
+
+    # ------------------------------------------------------------------ sparse pyramidal Lucas-Kanade
+    def lk(self, prev, next, pts, next_pts=None, **lk_kw):
+        """cv2.calcOpticalFlowPyrLK(prev, next, pts, next_pts, winSize=, maxLevel=, criteria=, flags=, minEigThreshold=)
+        -> (next_pts float32[n,2], status uint8[n], err float32[n])."""
+        prev, next = _as_gray(prev, "prevImg"), _as_gray(next, "nextImg")
+        if prev.shape != next.shape:
+            raise ValueError(f"prevImg and nextImg must have the same size, got {prev.shape} and {next.shape}")
+        prev, next = np.ascontiguousarray(prev), np.ascontiguousarray(next)
+        h, w = prev.shape
+        p = make_lk_params(**lk_kw)
+        pts = np.ascontiguousarray(np.asarray(pts, np.float32).reshape(-1, 2))
+        n = len(pts)
+        if p.flags & OPTFLOW_USE_INITIAL_FLOW:
+            if next_pts is None or np.size(next_pts) != 2 * n:
+                raise ValueError("OPTFLOW_USE_INITIAL_FLOW needs nextPts with one guess per point")
+            out = np.array(np.asarray(next_pts, np.float32).reshape(-1, 2), order="C")
+        else:
+            out = np.zeros((n, 2), np.float32)
+        status = np.zeros(n, np.uint8)
+        err = np.zeros(n, np.float32)
+        _check(self._lib.ofarn_lk_calc(self._h, prev.ctypes.data_as(_u8p), next.ctypes.data_as(_u8p), w, h, w,
+                                       pts.ctypes.data_as(_fp), n, C.byref(p), out.ctypes.data_as(_fp),
+                                       status.ctypes.data_as(_u8p), err.ctypes.data_as(_fp)))
+        return out, status, err
+
+    def lk_batch_device(self, d_frames, n_frames, width, height, pairs_mode, d_pts, npts, d_next_pts, d_status, d_err,
+                        reverse=False, pts_per_pair=False, stream=None, **lk_kw):
+        """Device-resident LK for a stack of frames: pair p tracks the npts points from its first frame to its second
+        (reverse=True: from the second to the first, as pathfinder_viewer.py:156)."""
+        p = make_lk_params(**lk_kw)
+        _check(self._lib.ofarn_lk_calc_batch_device(self._h, _ptr(d_frames), n_frames, width, height, pairs_mode,
+                                                    int(bool(reverse)), _ptr(d_pts), npts, int(bool(pts_per_pair)),
+                                                    C.byref(p), _ptr(d_next_pts), _ptr(d_status), _ptr(d_err),
+                                                    C.c_void_p(stream) if stream else None))
+
+    def vector_filter(self, vecs, width, height, return_flow=False):
+        """pathfinder_viewer.py:159-176 + 204-217 on vectors given AT the grid points (float32[P,2] or [n,P,2]),
+        e.g. next_pts - points_ of get_flow_lk."""
+        v_ = np.ascontiguousarray(vecs, np.float32)
+        single = v_.ndim == 2
+        v_ = v_[None] if single else v_
+        n, P, two = v_.shape
+        if two != 2 or P != len(grid_points(width, height, self.params.grid_step)):
+            raise ValueError("vecs must be float32[..., P, 2] with P = number of grid points")
+        mask = np.zeros((n, P), np.uint8)
+        val = np.zeros((n, P), np.uint8)
+        iflow = np.zeros((n, P, 2), np.int32) if return_flow else None
+        _check(self._lib.ofarn_vector_filter(self._h, v_.ctypes.data_as(_fp), n, width, height, mask.ctypes.data_as(_u8p),
+                                             val.ctypes.data_as(_u8p),
+                                             iflow.ctypes.data_as(C.POINTER(C.c_int32)) if return_flow else None))
+        if return_flow:
+            return (mask[0], val[0], iflow[0]) if single else (mask, val, iflow)
+        return (mask[0], val[0]) if single else (mask, val)
+
+    def vector_filter_device(self, d_vecs, n, width, height, d_mask, d_v, d_iflow=None, stream=None):
+        _check(self._lib.ofarn_vector_filter_device(self._h, _ptr(d_vecs), n, width, height, _ptr(d_mask), _ptr(d_v),
+                                                    _ptr(d_iflow), C.c_void_p(stream) if stream else None))
+
+    def stage_pyrdown(self, img):
+        img = np.ascontiguousarray(_as_gray(img, "img"))
+        h, w = img.shape
+        out = np.empty(((h + 1) // 2, (w + 1) // 2), np.uint8)
+        _check(self._lib.ofarn_stage_pyrdown(self._h, img.ctypes.data_as(_u8p), w, h, out.ctypes.data_as(_u8p)))
+        return out
+
+    def stage_scharr(self, img):
+        img = np.ascontiguousarray(_as_gray(img, "img"))
+        h, w = img.shape
+        out = np.empty((h, w, 2), np.int16)
+        _check(self._lib.ofarn_stage_scharr(self._h, img.ctypes.data_as(_u8p), w, h, out.ctypes.data_as(C.POINTER(C.c_int16))))
+        return out
 
     # ------------------------------------------------------------------ front end and visualisers, host memory
     def bgr2gray(self, img):
@@ -512,6 +619,35 @@ def calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, itera
     """cv2.calcOpticalFlowFarneback with cv2's positional order (DenseOF.py:147-156)."""
     return calculate_optical_flow(prev, next, flow, pyr_scale, levels, winsize, iterations, poly_n,
                                   poly_sigma, flags)
+
+
+def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 21), maxLevel=3,
+                         criteria=(TERM_CRITERIA_COUNT | TERM_CRITERIA_EPS, 30, 0.01), flags=0, minEigThreshold=1e-4, device=0):
+    """cv2.calcOpticalFlowPyrLK with cv2's names and defaults (pathfinder_viewer.py:156, DenseOF.py:183, SparseOF.py:35).
+    Returns (nextPts, status, err): nextPts float32 shaped like prevPts, status uint8[n,1], err float32[n,1]."""
+    a = _as_gray(prevImg, "prevImg")
+    eng = _engine_for(a.shape[0], a.shape[1], device)
+    shape = np.shape(prevPts)
+    nxt, st, err = eng.lk(prevImg, nextImg, prevPts, nextPts, winSize=winSize, maxLevel=maxLevel, criteria=criteria,
+                          flags=flags, minEigThreshold=minEigThreshold)
+    return nxt.reshape(shape), st.reshape(-1, 1), err.reshape(-1, 1)
+
+
+def get_flow_lk(img1, img2, points_, device=0):
+    """pathfinder_viewer.py:144-201 ``get_flow_lk`` without the drawing: LK from img2 back to img1 at the grid points
+    (winSize 45, maxLevel 2, 10 iterations / 0.03), equalised moduli, median / 99-percentile gate.
+    Returns (None, flow int32[K,2], points_ int32[K,2]) -- the reference's frame_layer is host drawing of those."""
+    a = _as_gray(img1, "img1")
+    h, w = a.shape
+    pts = np.ascontiguousarray(np.asarray(points_, np.float32).reshape(-1, 2))
+    eng = _engine_for(h, w, device, grid_step=int(round(float(pts[1, 1] - pts[0, 1]))) if len(pts) > 1 and pts[1, 0] == pts[0, 0] else 30)
+    if not np.array_equal(pts, grid_points(w, h, eng.params.grid_step)):
+        raise ValueError("points_ must be the measurement grid of pathfinder_viewer.py:255-267 for this frame size")
+    nxt, _st, _err = eng.lk(img2, img1, pts, None, winSize=(45, 45), maxLevel=2,
+                            criteria=(TERM_CRITERIA_EPS | TERM_CRITERIA_COUNT, 10, 0.03))
+    mask, _v, iflow = eng.vector_filter(nxt - pts, w, h, return_flow=True)
+    keep = mask.astype(bool)
+    return None, iflow[keep], np.int32(pts + 0.5)[keep]
 
 
 def cvtColor_bgr2gray(img, device=0):

@@ -125,6 +125,43 @@ int ofarn_flow_arrows(ofarn_ctx *ctx, const float *h_flow, int n, int w, int h, 
 int ofarn_flow_arrows_device(ofarn_ctx *ctx, const float *d_flow, int n, int w, int h, int step,
                              int32_t *d_lines, void *hip_stream);
 
+/* ---- sparse pyramidal Lucas-Kanade -----------------------------------------
+ * cv2.calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts, winSize, maxLevel, criteria, flags,
+ * minEigThreshold) as pathfinder_viewer.py:153-158, DenseOF.py:181-185 and SparseOF.py:35-36 call it
+ * (OpenCV 4.10 lkpyramid.cpp: buildOpticalFlowPyramid, calcScharrDeriv, LKTrackerInvoker).  The tracker's
+ * float sums are taken per window column, then over the columns (oracle OFO_LK_SUM_COLUMNS). */
+#define OFARN_LK_USE_INITIAL_FLOW 4    /* cv2.OPTFLOW_USE_INITIAL_FLOW: next_pts holds the initial guesses */
+#define OFARN_LK_GET_MIN_EIGENVALS 8   /* cv2.OPTFLOW_LK_GET_MIN_EIGENVALS: err = minimum eigenvalue measure */
+typedef struct ofarn_lk_params {
+    int win_w, win_h;         /* winSize, each > 2; up to 64 x 255                  default 21 x 21 */
+    int max_level;            /* pyramid levels above level 0                       default 3       */
+    int max_count;            /* criteria COUNT (clamped to 0..100)                 default 30      */
+    double epsilon;           /* criteria EPS (clamped to 0..10)                    default 0.01    */
+    int flags;                /* OR of OFARN_LK_*                                   default 0       */
+    double min_eig_threshold; /*                                                    default 1e-4    */
+} ofarn_lk_params;
+void ofarn_lk_default_params(ofarn_lk_params *p);
+/* Number of pyramid levels above level 0 that buildOpticalFlowPyramid keeps for this size (<= max_level). */
+int ofarn_lk_levels(const ofarn_lk_params *p, int w, int h);
+/* One pair, host memory; synchronous.  h_pts, h_next_pts float32[npts][2]; h_status uint8[npts]; h_err
+ * float32[npts].  Replaces cv2.calcOpticalFlowPyrLK(prev, next, pts, None, ...). */
+int ofarn_lk_calc(ofarn_ctx *ctx, const uint8_t *h_prev, const uint8_t *h_next, int w, int h, int stride,
+                  const float *h_pts, int npts, const ofarn_lk_params *p, float *h_next_pts,
+                  uint8_t *h_status, float *h_err);
+/* A batch of frames on the device (pairs as in ofarn_calc_batch_device).  d_pts: float32[npts][2] shared
+ * by all pairs (pts_per_pair = 0) or float32[n_pairs][npts][2]; reverse != 0 tracks from the later frame
+ * of a pair to the earlier one, as pathfinder_viewer.py:156 does.  Outputs [n_pairs][npts](x2). */
+int ofarn_lk_calc_batch_device(ofarn_ctx *ctx, const uint8_t *d_frames, int n_frames, int w, int h,
+                               int pairs_mode, int reverse, const float *d_pts, int npts, int pts_per_pair,
+                               const ofarn_lk_params *p, float *d_next_pts, uint8_t *d_status,
+                               float *d_err, void *hip_stream);
+/* The vector filter + V of pathfinder_viewer.py:159-176, 204-217 on vectors GIVEN at the context's grid
+ * points (flow_ = next_pts - points_ of get_flow_lk): vecs float32[n][P][2]. */
+int ofarn_vector_filter(ofarn_ctx *ctx, const float *h_vecs, int n, int w, int h, uint8_t *h_mask,
+                        uint8_t *h_v, int32_t *h_iflow);
+int ofarn_vector_filter_device(ofarn_ctx *ctx, const float *d_vecs, int n, int w, int h, uint8_t *d_mask,
+                               uint8_t *d_v, int32_t *d_iflow, void *hip_stream);
+
 /* Measurement grid of pathfinder_viewer.py:255-267.  Returns P (number of points, x-major order);
  * if h_pts != NULL writes float32[P][2] = (x, y). */
 int ofarn_grid_points(int w, int h, int step, float *h_pts);
@@ -184,6 +221,9 @@ int ofarn_stage_update_matrices(ofarn_ctx *ctx, const float *h_R0, const float *
 int ofarn_stage_blur_solve(ofarn_ctx *ctx, const float *h_M, int w, int h, float *h_flow);
 int ofarn_stage_flow_upsample(ofarn_ctx *ctx, const float *h_flow, int sw, int sh, int dw, int dh,
                               float *h_out);
+/* cv2.pyrDown on uint8 (out: ((w+1)/2) x ((h+1)/2)) and calcScharrDeriv (out: int16[h][w][2]) of the LK path */
+int ofarn_stage_pyrdown(ofarn_ctx *ctx, const uint8_t *h_img, int w, int h, uint8_t *h_out);
+int ofarn_stage_scharr(ofarn_ctx *ctx, const uint8_t *h_img, int w, int h, int16_t *h_out);
 /* resize(flow, INTER_AREA) * mul, shrinking only (the coarsest-level start of USE_INITIAL_FLOW) */
 int ofarn_stage_resize_area(ofarn_ctx *ctx, const float *h_flow, int sw, int sh, int dw, int dh, float mul,
                             float *h_out);

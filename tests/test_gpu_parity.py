@@ -503,3 +503,131 @@ def test_draw_flow_lines_bit_exact(H, oracle, h, w, step):
     got = H.flow_lines(flow, step)
     assert got.dtype == np.int32 and got.shape == ref.shape
     np.testing.assert_array_equal(got, ref)
+
+
+# ------------------------------------------------------------------------------------ sparse pyramidal LK
+@pytest.mark.parametrize("h,w", [(37, 53), (270, 481), (1, 7), (6, 1), (1080, 1920)])
+def test_lk_pyrdown_and_scharr_bit_exact(H, oracle, h, w):
+    rng = np.random.default_rng(h + w)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    with H.FarnebackEngine(w, h, 1) as eng:
+        np.testing.assert_array_equal(eng.stage_pyrdown(img), oracle.pyrdown_u8(img))
+        np.testing.assert_array_equal(eng.stage_scharr(img), oracle.scharr_deriv(img))
+
+
+LK_CASES = [
+    # (w, h, seed, points, kwargs)  -- first row: the call of pathfinder_viewer.py:156 / DenseOF.py:183
+    (480, 270, 5, "grid30", dict(winSize=(45, 45), maxLevel=2, criteria=(3, 10, 0.03))),
+    (320, 240, 6, "grid30", dict(winSize=(15, 15), maxLevel=2, criteria=(3, 10, 0.03))),          # SparseOF.py:6-8
+    (333, 251, 7, "random", dict()),                                                              # cv2 defaults
+    (200, 150, 8, "random", dict(winSize=(31, 17), maxLevel=1, criteria=(1, 5, 0.0))),             # COUNT only, non-square
+    (200, 150, 9, "random", dict(winSize=(9, 9), maxLevel=4, criteria=(2, 0, 0.001))),             # EPS only -> 30 iterations
+    (160, 120, 10, "random", dict(winSize=(21, 21), maxLevel=0, flags=8)),                         # OPTFLOW_LK_GET_MIN_EIGENVALS
+    (100, 90, 11, "random", dict(winSize=(63, 63), maxLevel=3)),                                   # window barely fits level 0
+]
+
+
+def _lk_points(kind, w, h, oracle, seed):
+    if kind == "grid30":
+        return oracle.grid_points_numpy(w, h, 30)
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform((-5, -5), (w + 5, h + 5), (300, 2)).astype(np.float32)
+    pts[0] = (-200, 10)           # far outside: status 0
+    pts[1] = (w - 1, h - 1)       # corner: window mostly in the border
+    pts[2] = (0, 0)
+    return pts
+
+
+@pytest.mark.parametrize("w,h,seed,kind,kw", LK_CASES)
+def test_lk_vs_oracle(H, oracle, w, h, seed, kind, kw):
+    a, b, _ = translated_pair(h, w, seed, max_shift=5)
+    pts = _lk_points(kind, w, h, oracle, seed)
+    got_n, got_s, got_e = H.calcOpticalFlowPyrLK(a, b, pts, None, **kw)
+    assert got_n.shape == pts.shape and got_s.shape == (len(pts), 1) and got_e.shape == (len(pts), 1)
+    okw = dict(kw)
+    ctype, cnt, eps = okw.pop("criteria", (3, 30, 0.01))
+    okw["criteria"] = (cnt if ctype & 1 else 30, eps if ctype & 2 else 0.01)
+    ref_n, ref_s, ref_e = oracle.calc_optical_flow_pyr_lk(a, b, pts, None, sum_mode=oracle.LK_SUM_COLUMNS, **okw)
+    np.testing.assert_array_equal(got_s[:, 0], ref_s)
+    np.testing.assert_array_equal(got_n, ref_n)
+    np.testing.assert_array_equal(got_e[:, 0], ref_e)
+    # OpenCV's scalar summation order: same status, positions within tolerance (float sums of ~2000 terms)
+    sc_n, sc_s, _ = oracle.calc_optical_flow_pyr_lk(a, b, pts, None, sum_mode=oracle.LK_SUM_SCALAR, **okw)
+    np.testing.assert_array_equal(got_s[:, 0], sc_s)
+    d = np.abs(got_n - sc_n)[got_s[:, 0] == 1]
+    if len(d):
+        assert np.quantile(d, 0.99) < 5e-3 and d.max() < 0.1, (np.quantile(d, 0.99), d.max())
+
+
+def test_lk_initial_flow_and_flat_image(H, oracle):
+    a, b, (tx, ty) = translated_pair(150, 200, 21, max_shift=4)
+    pts = np.random.default_rng(3).uniform((20, 20), (180, 130), (50, 2)).astype(np.float32)
+    guess = (pts + (tx, ty) + 0.3).astype(np.float32)
+    kw = dict(winSize=(15, 15), maxLevel=1, criteria=(3, 20, 0.01), flags=H.OPTFLOW_USE_INITIAL_FLOW)
+    got = H.calcOpticalFlowPyrLK(a, b, pts, guess.copy(), **kw)
+    ref = oracle.calc_optical_flow_pyr_lk(a, b, pts, guess.copy(), winSize=(15, 15), maxLevel=1, criteria=(20, 0.01),
+                                          flags=oracle.LK_USE_INITIAL_FLOW, sum_mode=oracle.LK_SUM_COLUMNS)
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1][:, 0], ref[1])
+    with pytest.raises(ValueError):
+        H.calcOpticalFlowPyrLK(a, b, pts, None, **kw)
+    flat = np.full((150, 200), 90, np.uint8)
+    n, s, e = H.calcOpticalFlowPyrLK(flat, flat, pts)
+    assert not s.any() and np.array_equal(n, pts)
+    with pytest.raises(ValueError):
+        H.calcOpticalFlowPyrLK(a, b, pts, None, winSize=(2, 2))
+    with pytest.raises(ValueError):
+        H.calcOpticalFlowPyrLK(a, b[:, :-1], pts)
+
+
+def test_lk_batch_device_and_get_flow_lk(H, oracle):
+    torch = pytest.importorskip("torch")
+    h, w, n_frames = 270, 480, 5
+    frames, _ = translated_pairs(3, h, w, 7100, max_shift=5)
+    frames = frames[:n_frames]
+    pts = oracle.grid_points_numpy(w, h, 30)
+    P = len(pts)
+    d_frames = torch.from_numpy(frames).cuda()
+    d_pts = torch.from_numpy(pts).cuda()
+    lk = dict(winSize=(45, 45), maxLevel=2, criteria=(3, 10, 0.03))
+    with H.FarnebackEngine(w, h, 2) as eng:                       # waves of 2 pairs
+        for mode, n_pairs in ((H.PAIRS_CONSECUTIVE, n_frames - 1), (H.PAIRS_INDEPENDENT, n_frames // 2)):
+            d_next = torch.zeros((n_pairs, P, 2), dtype=torch.float32, device="cuda")
+            d_st = torch.zeros((n_pairs, P), dtype=torch.uint8, device="cuda")
+            d_err = torch.zeros((n_pairs, P), dtype=torch.float32, device="cuda")
+            eng.lk_batch_device(d_frames, n_frames if mode == H.PAIRS_CONSECUTIVE else 2 * n_pairs, w, h, mode, d_pts, P,
+                                d_next, d_st, d_err, reverse=True, **lk)
+            d_mask = torch.zeros((n_pairs, P), dtype=torch.uint8, device="cuda")
+            d_v = torch.zeros_like(d_mask)
+            eng.vector_filter_device(d_next - d_pts, n_pairs, w, h, d_mask, d_v)
+            torch.cuda.synchronize()
+            for i in range(n_pairs):
+                f1, f2 = (frames[i], frames[i + 1]) if mode == H.PAIRS_CONSECUTIVE else (frames[2 * i], frames[2 * i + 1])
+                # pathfinder_viewer.py:156: calcOpticalFlowPyrLK(img2, img1, ...) -- from the later frame to the earlier
+                ref_n, ref_s, ref_e = oracle.calc_optical_flow_pyr_lk(f2, f1, pts, None, winSize=(45, 45), maxLevel=2,
+                                                                      criteria=(10, 0.03), sum_mode=oracle.LK_SUM_COLUMNS)
+                np.testing.assert_array_equal(d_next[i].cpu().numpy(), ref_n)
+                np.testing.assert_array_equal(d_st[i].cpu().numpy(), ref_s)
+                np.testing.assert_array_equal(d_err[i].cpu().numpy(), ref_e)
+                mask, iflow, ipts, _ = oracle.get_flow_lk_numpy(f1, f2, pts, w, h, next_pts=ref_n)
+                np.testing.assert_array_equal(d_mask[i].cpu().numpy().astype(bool), mask)
+    # the reference's function, same name: (frame_layer, flow, points_)
+    layer, flow, kept = H.get_flow_lk(frames[0], frames[1], pts)
+    ref_n, _, _ = oracle.calc_optical_flow_pyr_lk(frames[1], frames[0], pts, None, winSize=(45, 45), maxLevel=2,
+                                                  criteria=(10, 0.03), sum_mode=oracle.LK_SUM_COLUMNS)
+    mask, iflow, ipts, _ = oracle.get_flow_lk_numpy(frames[0], frames[1], pts, w, h, next_pts=ref_n)
+    assert layer is None and flow.dtype == np.int32
+    np.testing.assert_array_equal(kept, ipts[mask])
+    assert (flow != iflow[mask]).any(axis=1).sum() <= 1          # cos/sin last-ulp at an integer truncation, as in the dense filter
+
+
+def test_lk_1080p_grid(H, oracle):
+    a, b, (tx, ty) = translated_pair(1080, 1920, 2001, max_shift=8)
+    pts = H.grid_points(1920, 1080, 30)
+    n, s, e = H.calcOpticalFlowPyrLK(b, a, pts, None, winSize=(45, 45), maxLevel=2, criteria=(3, 10, 0.03))
+    ref_n, ref_s, ref_e = oracle.calc_optical_flow_pyr_lk(b, a, pts, None, winSize=(45, 45), maxLevel=2, criteria=(10, 0.03),
+                                                          sum_mode=oracle.LK_SUM_COLUMNS)
+    np.testing.assert_array_equal(n, ref_n)
+    np.testing.assert_array_equal(s[:, 0], ref_s)
+    inner = (pts[:, 0] > 100) & (pts[:, 0] < 1820) & (pts[:, 1] > 100) & (pts[:, 1] < 980)
+    assert np.abs(n[inner] - pts[inner] + (tx, ty)).max() < 0.05          # tracked backwards: flow = -(tx, ty)
