@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Throughput of the sparse LK path (pathfinder_viewer.py:153-176) on synthetic 1080p pairs, device resident.
+
+    python tools/lkbench.py [--batch 64] [--reps 3]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--cpu", type=int, default=2, help="pairs timed on the CPU oracle (0 = skip)")
+    a = ap.parse_args()
+    import torch
+    import hackathonopticalflow_amd as ofa
+    from hackathonopticalflow_amd.synth import translated_pairs
+    W, H = 1920, 1080
+    uniq = min(4, a.batch)
+    fr, _ = translated_pairs(uniq, H, W, 3000)
+    fr_d = torch.from_numpy(fr).cuda()
+    frames = torch.empty((2 * a.batch, H, W), dtype=torch.uint8, device="cuda")
+    for i in range(a.batch):
+        frames[2 * i:2 * i + 2] = fr_d[2 * (i % uniq):2 * (i % uniq) + 2]
+    pts = ofa.grid_points(W, H, 30)
+    P = len(pts)
+    d_pts = torch.from_numpy(pts).cuda()
+    d_next = torch.zeros((a.batch, P, 2), dtype=torch.float32, device="cuda")
+    d_st = torch.zeros((a.batch, P), dtype=torch.uint8, device="cuda")
+    d_err = torch.zeros((a.batch, P), dtype=torch.float32, device="cuda")
+    d_mask = torch.zeros((a.batch, P), dtype=torch.uint8, device="cuda")
+    d_v = torch.zeros_like(d_mask)
+    eng = ofa.FarnebackEngine(W, H, min(a.batch, 64), 0)
+    st = torch.cuda.current_stream().cuda_stream
+    lk = dict(winSize=(45, 45), maxLevel=2, criteria=(3, 10, 0.03))
+
+    def run():
+        eng.lk_batch_device(frames, 2 * a.batch, W, H, ofa.PAIRS_INDEPENDENT, d_pts, P, d_next, d_st, d_err, reverse=True,
+                            stream=st, **lk)
+        eng.vector_filter_device(d_next - d_pts, a.batch, W, H, d_mask, d_v, stream=st)
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.reps
+    print(f"LK + filter, {P} points, winSize 45, maxLevel 2: {dt * 1e3:.2f} ms per {a.batch} pairs -> {a.batch / dt:.1f} pairs/s")
+    if a.cpu:
+        from oracle import oracle as O
+        O.build()
+        f = fr[:2 * min(a.cpu, uniq)]
+        t0 = time.perf_counter()
+        for i in range(len(f) // 2):
+            O.calc_optical_flow_pyr_lk(f[2 * i + 1], f[2 * i], pts, None, winSize=(45, 45), maxLevel=2, criteria=(10, 0.03))
+        dc = (time.perf_counter() - t0) / (len(f) // 2)
+        print(f"CPU oracle (one thread): {dc * 1e3:.1f} ms per pair -> {1 / dc:.2f} pairs/s")
+
+
+if __name__ == "__main__":
+    main()
