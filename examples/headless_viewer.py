@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""The frame loop of the reference's viewers without the GUI, on the MI355X path.
+
+What DenseOF.py:491-525 and pathfinder_viewer.py do per frame (decode, cvtColor, calcOpticalFlowFarneback or
+calcOpticalFlowPyrLK, vector filter, draw_hsv / draw_flow / draw_sparse_lamps) is run here on a stack of BGR frames
+that is already on the GPU; what comes back per frame pair is small: the danger mask and V of the grid points, the
+int32 arrow end points, optionally the HSV rainbow.  Drawing the overlays (cv2.polylines / cv2.circle) stays with
+the caller.
+
+    python examples/headless_viewer.py [--frames 9] [--width 640 --height 480]
+
+Synthetic input (a textured scene panning by an integer shift per frame); real video decoding is out of scope.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def synthetic_video(n, h, w, seed=1):
+    """BGR frames uint8[n,h,w,3] of one smooth random scene panning by (2, 1) px per frame."""
+    from hackathonopticalflow_amd.synth import translated_pair
+    pad = 4 * n + 16
+    base, _, _ = translated_pair(h + 2 * pad, w + 2 * pad, seed, max_shift=0)
+    frames = np.empty((n, h, w, 3), np.uint8)
+    for i in range(n):
+        g = base[pad - i:pad - i + h, pad - 2 * i:pad - 2 * i + w]
+        frames[i] = np.stack([g, np.roll(g, 3, axis=1), 255 - g], -1)
+    return frames
+
+
+def run(frames_bgr, device=0, step=30, want_hsv=True):
+    """Returns a dict of per-pair results for the consecutive pairs of the stack (all NumPy, small)."""
+    import torch
+    import hackathonopticalflow_amd as ofa
+    n, h, w, _ = frames_bgr.shape
+    n_pairs = n - 1
+    dev = torch.device("cuda", device)
+    d_bgr = torch.from_numpy(frames_bgr).to(dev)
+    pts = ofa.grid_points(w, h, step)
+    P = len(pts)
+    K = ofa.load_library().ofarn_flow_arrow_count(w, h, 14, None, None)
+    d_flow = torch.empty((n_pairs, h, w, 2), dtype=torch.float32, device=dev)
+    d_mask = torch.zeros((n_pairs, P), dtype=torch.uint8, device=dev)
+    d_v = torch.zeros_like(d_mask)
+    d_lines = torch.zeros((n_pairs, K, 2, 2), dtype=torch.int32, device=dev)
+    d_rainbow = torch.empty((n_pairs, h, w, 3), dtype=torch.uint8, device=dev) if want_hsv else None
+    d_gray = torch.empty((n, h, w), dtype=torch.uint8, device=dev)
+    d_pts = torch.from_numpy(pts).to(dev)
+    d_next = torch.zeros((n_pairs, P, 2), dtype=torch.float32, device=dev)
+    d_st = torch.zeros((n_pairs, P), dtype=torch.uint8, device=dev)
+    d_err = torch.zeros((n_pairs, P), dtype=torch.float32, device=dev)
+    d_lk_mask = torch.zeros_like(d_mask)
+    d_lk_v = torch.zeros_like(d_mask)
+    d_lk_flow = torch.zeros((n_pairs, P, 2), dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    with ofa.FarnebackEngine(w, h, max(1, min(n_pairs, 64)), device, grid_step=step) as eng:      # DenseOF.py defaults
+        # dense path: DenseOF.py:510 (cvtColor) + :520 (Farneback) + the grid filter, video order (prev_gray = gray)
+        eng.calc_batch_device(d_bgr, n, w, h, ofa.PAIRS_CONSECUTIVE, d_flow, d_mask, d_v, stream=st, bgr=True)
+        eng.flow_arrows_device(d_flow, n_pairs, w, h, 14, d_lines, stream=st)                      # draw_flow's lines
+        if want_hsv:
+            eng.flow_hsv_device(d_flow, n_pairs, w, h, None, d_rainbow, stream=st)                 # draw_hsv
+        # sparse path of pathfinder_viewer.py: LK from the later frame back to the earlier one, then the same filter
+        eng.bgr2gray_device(d_bgr, n, w, h, d_gray, stream=st)
+        eng.lk_batch_device(d_gray, n, w, h, ofa.PAIRS_CONSECUTIVE, d_pts, P, d_next, d_st, d_err, reverse=True, stream=st,
+                            winSize=(45, 45), maxLevel=2, criteria=(3, 10, 0.03))
+        eng.vector_filter_device(d_next - d_pts, n_pairs, w, h, d_lk_mask, d_lk_v, d_lk_flow, stream=st)
+        torch.cuda.synchronize()
+    return dict(points=pts, dense_mask=d_mask.cpu().numpy(), dense_v=d_v.cpu().numpy(), lines=d_lines.cpu().numpy(),
+                rainbow=None if d_rainbow is None else d_rainbow.cpu().numpy(), lk_mask=d_lk_mask.cpu().numpy(),
+                lk_v=d_lk_v.cpu().numpy(), lk_flow=d_lk_flow.cpu().numpy(), lk_status=d_st.cpu().numpy(),
+                mean_flow=d_flow.mean(dim=(1, 2)).cpu().numpy())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=9)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    a = ap.parse_args()
+    out = run(synthetic_video(a.frames, a.height, a.width))
+    for i in range(a.frames - 1):
+        print(f"pair {i}: mean dense flow {out['mean_flow'][i].round(3)}  danger points dense {int(out['dense_mask'][i].sum())}"
+              f" / LK {int(out['lk_mask'][i].sum())} of {len(out['points'])}  LK tracked {int(out['lk_status'][i].sum())}")
+
+
+if __name__ == "__main__":
+    main()

@@ -631,3 +631,21 @@ def test_lk_1080p_grid(H, oracle):
     np.testing.assert_array_equal(s[:, 0], ref_s)
     inner = (pts[:, 0] > 100) & (pts[:, 0] < 1820) & (pts[:, 1] > 100) & (pts[:, 1] < 980)
     assert np.abs(n[inner] - pts[inner] + (tx, ty)).max() < 0.05          # tracked backwards: flow = -(tx, ty)
+
+
+# ------------------------------------------------------------------------------------ the viewers' frame loop, headless
+def test_headless_viewer_example(H):
+    pytest.importorskip("torch")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "headless_viewer", os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples", "headless_viewer.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    frames = mod.synthetic_video(5, 240, 320)
+    out = mod.run(frames)
+    P = len(out["points"])
+    assert out["dense_mask"].shape == (4, P) and out["lk_mask"].shape == (4, P) and out["rainbow"].shape == (4, 240, 320, 3)
+    # the scene pans by (2, 1) px per frame
+    assert np.abs(out["mean_flow"] - (2, 1)).max() < 0.3          # whole-frame mean: the borders pull it down a little
+    assert out["lk_status"].all()
+    assert np.abs(np.median(out["lines"][:, :, 1] - out["lines"][:, :, 0], axis=1) - (-2, -1)).max() <= 1
