@@ -643,6 +643,9 @@ int ofarn_create(const ofarn_params *params, int device, int max_w, int max_h, i
     if (rc) return rc;
     if (max_w < 1 || max_h < 1 || max_batch < 1)
         return fail(OFARN_E_INVALID, "max_w, max_h, max_batch must be >= 1 (got %d, %d, %d)", max_w, max_h, max_batch);
+    // the kernels address a frame's planes with 32-bit byte offsets (16 bytes per pixel in the widest plane)
+    if ((unsigned long long)max_w * (unsigned long long)max_h >= (1ull << 27))
+        return fail(OFARN_E_SIZE, "frames of %dx%d exceed the 2^27-pixel limit of the 32-bit plane offsets", max_w, max_h);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(OFARN_E_HIP, "no HIP device visible; libofarn has no CPU path");

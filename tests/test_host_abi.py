@@ -72,6 +72,28 @@ def test_parameter_validation_without_gpu():
     assert (nx.value, ny.value) == (137, 77)
 
 
+def test_create_rejects_oversized_frames_before_touching_the_gpu():
+    lib = H.load_library()
+    h = ctypes.c_void_p()
+    p = H.make_params()
+    assert lib.ofarn_create(ctypes.byref(p), 0, 20000, 20000, 1, ctypes.byref(h)) == ofarn.OFARN_E_SIZE
+    assert b"2^27" in lib.ofarn_last_error() and not h.value
+
+
+def test_lk_parameter_validation_without_gpu():
+    lib = H.load_library()
+    p = H.OfarnLkParams()
+    lib.ofarn_lk_default_params(ctypes.byref(p))
+    assert (p.win_w, p.win_h, p.max_level, p.max_count, p.epsilon, p.flags, p.min_eig_threshold) == (21, 21, 3, 30, 0.01, 0, 1e-4)
+    assert lib.ofarn_lk_levels(ctypes.byref(H.make_lk_params(winSize=(45, 45), maxLevel=2)), 1920, 1080) == 2
+    assert lib.ofarn_lk_levels(ctypes.byref(H.make_lk_params(winSize=(45, 45), maxLevel=9)), 1920, 1080) == 4
+    assert lib.ofarn_lk_levels(ctypes.byref(H.make_lk_params(winSize=(2, 2))), 64, 64) == ofarn.OFARN_E_INVALID
+    assert lib.ofarn_lk_levels(ctypes.byref(H.make_lk_params(winSize=(99, 9))), 640, 480) == ofarn.OFARN_E_UNSUPPORTED
+    assert lib.ofarn_lk_levels(ctypes.byref(H.make_lk_params(flags=16)), 640, 480) == ofarn.OFARN_E_INVALID
+    # cv2 criteria semantics: a missing COUNT bit means 30 iterations, a missing EPS bit 0.01
+    assert H.make_lk_params(criteria=(2, 5, 0.5)).max_count == 30 and H.make_lk_params(criteria=(1, 5, 0.5)).epsilon == 0.01
+
+
 def test_input_validation_before_any_device_call():
     a = np.zeros((64, 64), np.uint8)
     with pytest.raises(ValueError):
