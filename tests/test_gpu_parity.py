@@ -649,3 +649,24 @@ def test_headless_viewer_example(H):
     assert np.abs(out["mean_flow"] - (2, 1)).max() < 0.3          # whole-frame mean: the borders pull it down a little
     assert out["lk_status"].all()
     assert np.abs(np.median(out["lines"][:, :, 1] - out["lines"][:, :, 0], axis=1) - (-2, -1)).max() <= 1
+
+
+def test_lk_batch_points_per_pair_and_forward_direction(H, oracle):
+    torch = pytest.importorskip("torch")
+    h, w, n_pairs, npts = 150, 200, 3, 40
+    frames, _ = translated_pairs(n_pairs, h, w, 8100, max_shift=3)
+    rng = np.random.default_rng(4)
+    pts = rng.uniform((10, 10), (w - 10, h - 10), (n_pairs, npts, 2)).astype(np.float32)
+    d_next = torch.zeros((n_pairs, npts, 2), dtype=torch.float32, device="cuda")
+    d_st = torch.zeros((n_pairs, npts), dtype=torch.uint8, device="cuda")
+    d_err = torch.zeros((n_pairs, npts), dtype=torch.float32, device="cuda")
+    with H.FarnebackEngine(w, h, 2) as eng:
+        eng.lk_batch_device(torch.from_numpy(frames).cuda(), 2 * n_pairs, w, h, H.PAIRS_INDEPENDENT, torch.from_numpy(pts).cuda(),
+                            npts, d_next, d_st, d_err, reverse=False, pts_per_pair=True, winSize=(21, 21), maxLevel=2)
+        torch.cuda.synchronize()
+    for i in range(n_pairs):
+        ref_n, ref_s, ref_e = oracle.calc_optical_flow_pyr_lk(frames[2 * i], frames[2 * i + 1], pts[i], None, winSize=(21, 21),
+                                                              maxLevel=2, sum_mode=oracle.LK_SUM_COLUMNS)
+        np.testing.assert_array_equal(d_next[i].cpu().numpy(), ref_n)
+        np.testing.assert_array_equal(d_st[i].cpu().numpy(), ref_s)
+        np.testing.assert_array_equal(d_err[i].cpu().numpy(), ref_e)
