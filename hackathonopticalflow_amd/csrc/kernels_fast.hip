@@ -486,7 +486,7 @@ __global__ __launch_bounds__(FI_THREADS) void k_polyexp_march(const void *__rest
         sRow[buf][0][tid] = r0;
         sRow[buf][1][tid] = r1;
         sRow[buf][2][tid] = r2;
-        __syncthreads();
+        barrier_lds_only();   // __syncthreads() would also drain vmcnt (the previous row's stores)
         if (tid >= N && tid < FI_THREADS - N && x < w) {
             const float *p0 = &sRow[buf][0][tid], *p1 = &sRow[buf][1][tid], *p2 = &sRow[buf][2][tid];
             const float g0 = c.g[0];
