@@ -279,6 +279,8 @@ struct ofarn_ctx {
     struct ProfRec { int stage, level; double units; hipEvent_t a, b; };
     bool prof_on = false;
     bool force_generic = false;   // OFARN_FORCE_GENERIC=1 or ofarn_set_option: use the unfused kernels only
+    int direct_min_frames = 32;   // k_level_direct marches long strips per thread: below this many frames in a wave the
+                                  // row-pass + column-pass pair has more parallelism and lower latency (OFARN_DIRECT_MIN_FRAMES)
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> prof_free;
     struct ProfAcc { int launches = 0; double ms = 0, units = 0; };
@@ -435,7 +437,8 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
         for (int k = nlev; k >= 0 && ok; k--) {
             const Level &L = c->lv[k];
             if (march0 && L.w == w && L.h == h && L.ksize == 3) continue;   // fused into the poly expansion
-            if (level_direct_supported(d_frames, w, h, L.w, L.h, L.ksize)) continue;   // built by k_level_direct, no tmp
+            if (nframes >= c->direct_min_frames && level_direct_supported(d_frames, w, h, L.w, L.h, L.ksize))
+                continue;   // built by k_level_direct, no tmp
             const size_t need = (size_t)nframes * h * L.w * 2;
             if (HL.n >= 12 || off + need > c->tmp_floats) { ok = false; break; }
             HL.lv[HL.n++] = HLevel{L.d_kern, L.d_xofs, ws.tmp + off, L.w, L.ksize};
@@ -476,7 +479,8 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
             timed(c, s, OFARN_STAGE_POLYEXP, k, ufr, [&] {
                 launch_polyexp_march(s, d_frames, fsz, 1, ws.R, L.w, L.h, nframes, c->poly, L.h_kern3);
             });
-        } else if (!c->force_generic && level_direct_supported(d_frames, w, h, L.w, L.h, L.ksize)) {
+        } else if (!c->force_generic && nframes >= c->direct_min_frames &&
+                   level_direct_supported(d_frames, w, h, L.w, L.h, L.ksize)) {
             // exact 1/2, 1/4, 1/8 levels: row pass + column pass + resize in one kernel straight from the frames
             timed(c, s, OFARN_STAGE_LEVEL_V, k, ufr, [&] {
                 launch_level_direct(s, d_frames, fsz, w, h, nframes, L.h_kern.data(), L.ksize, ws.I, L.w, L.h);
@@ -659,6 +663,7 @@ int ofarn_create(const ofarn_params *params, int device, int max_w, int max_h, i
         const char *e = getenv("OFARN_FORCE_GENERIC");
         c->force_generic = e && e[0] == '1';
     }
+    if (const char *e = getenv("OFARN_DIRECT_MIN_FRAMES")) c->direct_min_frames = atoi(e);
     if (!poly_prepare(params->poly_n, params->poly_sigma, c->poly)) {
         delete c;
         return fail(OFARN_E_INVALID, "poly_n out of range");

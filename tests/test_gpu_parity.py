@@ -368,6 +368,22 @@ def test_argument_errors(H):
         H.calculate_optical_flow(a, a, flags=4)        # OPTFLOW_USE_INITIAL_FLOW without `flow`
 
 
+def test_direct_level_kernels_in_the_pipeline(H, oracle, monkeypatch):
+    """k_level_direct (stage A of the 1/2, 1/4, 1/8 levels in one kernel) is chosen for waves of >= 32 frames; force it for
+    a single pair and for a small batch and compare the whole pipeline with the oracle bit for bit."""
+    monkeypatch.setenv("OFARN_DIRECT_MIN_FRAMES", "1")
+    for (w, h, levels) in ((640, 480, 3), (328, 248, 3), (1920, 1080, 5)):
+        a, b, _ = translated_pair(h, w, 41, max_shift=4)
+        with H.FarnebackEngine(w, h, 1, levels=levels) as eng:
+            np.testing.assert_array_equal(eng.calc(a, b), oracle.farneback(a, b, levels=levels, box_mode=oracle.BOX_BLOCKED))
+    frames, _ = translated_pairs(20, 120, 160, 9100, max_shift=3)
+    monkeypatch.setenv("OFARN_DIRECT_MIN_FRAMES", "32")
+    with H.FarnebackEngine(160, 120, 20, levels=2) as eng:              # 40 frames in one wave: direct by default
+        flow, _, _ = eng.calc_batch(frames, H.PAIRS_INDEPENDENT, want_danger=False)
+    for i in (0, 7, 19):
+        np.testing.assert_array_equal(flow[i], oracle.farneback(frames[2 * i], frames[2 * i + 1], levels=2, box_mode=oracle.BOX_BLOCKED))
+
+
 # ------------------------------------------------------------------------------------ SURVEY 8(f): front end
 @pytest.mark.parametrize("h,w", [(120, 160), (37, 53), (1, 1), (3, 5), (1080, 1920)])
 def test_bgr2gray_bit_exact(H, oracle, h, w):
