@@ -88,8 +88,10 @@ def make_frames_gpu(torch, n_pairs, seed0, device):
     return frames, shifts
 
 
-def cpu_baseline(frames_np, gpu_flow_np, n_sample):
-    """Times the CPU oracle on the first n_sample pairs: one thread, then OpenMP across pairs."""
+def cpu_baseline(frames_np, gpu_flow_np, n_sample, shifts=None):
+    """Times the CPU oracle on the first n_sample pairs: one thread, then OpenMP across pairs.
+    Also returns the endpoint errors of SURVEY 8(d): GPU vs oracle over all pixels, and both vs the ground truth
+    (the integer translation of the synthetic pair) on the interior, >= 32 px from the border."""
     from oracle import oracle as O
     O.build()
     fr = np.ascontiguousarray(frames_np[:2 * n_sample])
@@ -102,6 +104,12 @@ def cpu_baseline(frames_np, gpu_flow_np, n_sample):
     tn = time.perf_counter() - t0
     epe = np.linalg.norm(gpu_flow_np[:n_sample].astype(np.float64) - ref.astype(np.float64), axis=-1)
     assert np.array_equal(ref[0], ref1[0])
+    gt = None
+    if shifts is not None:
+        g = np.asarray(shifts[:n_sample], np.float64)[:, None, None, :]
+        inner = (slice(None), slice(32, -32), slice(32, -32))
+        gt = {"gpu_mean": float(np.linalg.norm(gpu_flow_np[:n_sample][inner] - g, axis=-1).mean()),
+              "cpu_oracle_mean": float(np.linalg.norm(ref[inner] - g, axis=-1).mean())}
     return {
         "value": round(n_sample / tn, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
         "sample": f"first {n_sample} pairs of the workload, oracle/farneback_oracle.c (OpenCV-algorithm CPU "
@@ -109,7 +117,7 @@ def cpu_baseline(frames_np, gpu_flow_np, n_sample):
                   f"{1 / t1:.4f} pairs/s on 1 pair",
         "single_thread_value": round(1 / t1, 4),
         "host_cpus": os.cpu_count(),
-    }, {"mean": float(epe.mean()), "p999": float(np.quantile(epe, 0.999)), "max": float(epe.max())}
+    }, {"mean": float(epe.mean()), "p999": float(np.quantile(epe, 0.999)), "max": float(epe.max())}, gt
 
 
 def main():
@@ -259,10 +267,12 @@ def main():
     }
     if world == 1 and args.cpu_sample > 0:
         ns = min(args.cpu_sample, uniq)
-        cb, epe = cpu_baseline(fr_u[:2 * ns].cpu().numpy(), flow[:ns].cpu().numpy(), ns)
+        cb, epe, gt = cpu_baseline(fr_u[:2 * ns].cpu().numpy(), flow[:ns].cpu().numpy(), ns, shifts)
         out["cpu_baseline"] = cb
         out["mean_epe_vs_cpu_oracle_px"] = epe["mean"]
         out["epe_vs_cpu_oracle"] = epe
+        if gt:
+            out["epe_vs_ground_truth_interior_px"] = gt
         out["speedup_vs_cpu_all_cores"] = round(value / cb["value"], 1)
         out["speedup_vs_cpu_1thread"] = round(value / cb["single_thread_value"], 1)
     print(json.dumps(out))
