@@ -42,6 +42,22 @@ int fail(int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                                  \
     } while (0)
 
+// device scratch that lives for one host-pointer call
+struct DevTmp {
+    void *p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+            return fail(OFARN_E_NOMEM, "device scratch of %zu bytes does not fit", bytes);
+        }
+        return OFARN_OK;
+    }
+    template <typename T> T *as() { return static_cast<T *>(p); }
+};
+
 inline int cv_round(double v) { return (int)lrint(v); }   // cvRound: half to even
 inline int cv_floor(float v) { int i = (int)v; return i - (i > v); }
 
@@ -880,22 +896,6 @@ int calc_batch_device_impl(ofarn_ctx *c, const uint8_t *d_frames, bool bgr, int 
     return OFARN_OK;
 }
 
-// device scratch that lives for one host-pointer call
-struct DevTmp {
-    void *p = nullptr;
-    ~DevTmp() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes)
-    {
-        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
-            (void)hipGetLastError();
-            p = nullptr;
-            return fail(OFARN_E_NOMEM, "device scratch of %zu bytes does not fit", bytes);
-        }
-        return OFARN_OK;
-    }
-    template <typename T> T *as() { return static_cast<T *>(p); }
-};
-
 // np.mgrid[step/2:size:step] (DenseOF.py:44): count and float start
 int arrow_axis(int size, int step, double *start)
 {
@@ -1187,8 +1187,9 @@ int ofarn_grid_filter(ofarn_ctx *c, const float *h_flow, int n, int w, int h, ui
     if (c->P == 0) return OFARN_OK;
     const size_t fsz = (size_t)w * h * 2 * sizeof(float);
     if ((rc = ensure_staging(c, 0, fsz, (size_t)c->P))) return rc;
-    int32_t *d_if = nullptr;
-    if (h_iflow) HIP_TRY(hipMalloc((void **)&d_if, (size_t)c->P * 2 * sizeof(int32_t)));
+    DevTmp iflow_tmp;
+    if (h_iflow && (rc = iflow_tmp.alloc((size_t)c->P * 2 * sizeof(int32_t)))) return rc;
+    int32_t *d_if = iflow_tmp.as<int32_t>();
     for (int i = 0; i < n; i++) {
         HIP_TRY(hipMemcpyAsync(c->st_flow, h_flow + (size_t)i * w * h * 2, fsz, hipMemcpyHostToDevice, c->stream));
         launch_grid_filter(c->stream, c->st_flow, w, h, 1, c->d_pts, c->P, c->prm.filter_variant, c->st_mask, c->st_v, d_if);
@@ -1199,7 +1200,6 @@ int ofarn_grid_filter(ofarn_ctx *c, const float *h_flow, int n, int w, int h, ui
                                    hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    if (d_if) (void)hipFree(d_if);
     return OFARN_OK;
 }
 
@@ -1559,12 +1559,12 @@ int ofarn_stage_flow_upsample(ofarn_ctx *c, const float *h_flow, int sw, int sh,
     std::vector<float> xa, ya;
     resize_tables(sw, dw, xo, xa);
     resize_tables(sh, dh, yo, ya);
-    int *d_xo = nullptr, *d_yo = nullptr;
-    float *d_xa = nullptr, *d_ya = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_xo, dw * sizeof(int)));
-    HIP_TRY(hipMalloc((void **)&d_xa, dw * sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&d_yo, dh * sizeof(int)));
-    HIP_TRY(hipMalloc((void **)&d_ya, dh * sizeof(float)));
+    DevTmp t_xo, t_xa, t_yo, t_ya;
+    if ((rc = t_xo.alloc(dw * sizeof(int))) || (rc = t_xa.alloc(dw * sizeof(float))) || (rc = t_yo.alloc(dh * sizeof(int))) ||
+        (rc = t_ya.alloc(dh * sizeof(float))))
+        return rc;
+    int *d_xo = t_xo.as<int>(), *d_yo = t_yo.as<int>();
+    float *d_xa = t_xa.as<float>(), *d_ya = t_ya.as<float>();
     HIP_TRY(hipMemcpy(d_xo, xo.data(), dw * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_xa, xa.data(), dw * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_yo, yo.data(), dh * sizeof(int), hipMemcpyHostToDevice));
@@ -1574,7 +1574,6 @@ int ofarn_stage_flow_upsample(ofarn_ctx *c, const float *h_flow, int sw, int sh,
                          (float)(1. / c->prm.pyr_scale));
     HIP_TRY(hipMemcpyAsync(h_out, c->ws[0].flowB, (size_t)dw * dh * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(d_xo); (void)hipFree(d_xa); (void)hipFree(d_yo); (void)hipFree(d_ya);
     return OFARN_OK;
 }
 

@@ -8,6 +8,7 @@ index sets bit-identical.  What is asserted here:
     max EPE <= 1e-3 px (TOL_* below) -- the only difference is the summation order of the box filter;
   * danger mask bit-exact against the reference's NumPy filter on the same flow.
 """
+import ast
 import glob
 import os
 
@@ -211,7 +212,7 @@ def test_full_size_properties_config3(H):
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_golden_fixtures(H, path):
     g = np.load(path, allow_pickle=False)
-    kw = dict(eval(str(g["params"])))
+    kw = dict(ast.literal_eval(str(g["params"])))
     got = H.calculate_optical_flow(g["prev"], g["next"], **kw)
     np.testing.assert_array_equal(got, g["flow_direct"])
     e = epe(got, g["flow_running"])
