@@ -678,7 +678,7 @@ __global__ __launch_bounds__(EDGE ? 64 : 256) void k_level_direct(const uint8_t 
         dy0 = sidx * strip;
         if (dy0 >= h || (w == 1 && (threadIdx.x & 1))) return;
     } else {
-        x = 1 + blockIdx.x * 256 + threadIdx.x;
+        x = 1 + blockIdx.x * blockDim.x + threadIdx.x;
         dy0 = blockIdx.y * strip;
         if (x > w - 2) return;
     }
@@ -772,9 +772,11 @@ static void launch_level_direct_sk(hipStream_t s, const uint8_t *frames, size_t 
     // strips of a multiple of three level rows; each strip re-does K+1-S row passes of warm-up
     const int units = (h + 2) / 3;
     if (w > 2) {
-        const int strip = 3 * best_strip_units(units, 3 * S, K + 1 - S, (int)cdivu(w - 2, 256) * nframes, 8);
-        dim3 grid(cdivu(w - 2, 256), cdivu(h, strip), nframes);
-        hipLaunchKernelGGL((k_level_direct<S, K, false>), grid, dim3(256), 0, s, frames, frame_stride, W, H, taps, I, w, h, strip);
+        // narrow levels: smaller blocks keep the lanes busy (a 80-column level fills 78 of 128 lanes, not of 256)
+        const int nt = w - 2 > 128 ? 256 : (w - 2 > 64 ? 128 : 64);
+        const int strip = 3 * best_strip_units(units, 3 * S, K + 1 - S, (int)cdivu(w - 2, nt) * nframes, 8 * (256 / nt));
+        dim3 grid(cdivu(w - 2, nt), cdivu(h, strip), nframes);
+        hipLaunchKernelGGL((k_level_direct<S, K, false>), grid, dim3(nt), 0, s, frames, frame_stride, W, H, taps, I, w, h, strip);
     }
     // border columns 0 and w-1: 32 strips of at least 12 rows per block of 64 threads
     int estrip = 3 * ((units + 31) / 32);
