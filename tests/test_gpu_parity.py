@@ -687,3 +687,34 @@ def test_lk_batch_points_per_pair_and_forward_direction(H, oracle):
         np.testing.assert_array_equal(d_next[i].cpu().numpy(), ref_n)
         np.testing.assert_array_equal(d_st[i].cpu().numpy(), ref_s)
         np.testing.assert_array_equal(d_err[i].cpu().numpy(), ref_e)
+
+
+# ------------------------------------------------------------------------------------ seeded fuzz over sizes and parameters
+def _fuzz_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        w = int(rng.choice([rng.integers(33, 420), 64 * rng.integers(1, 6), 8 * rng.integers(5, 50)]))
+        h = int(rng.choice([rng.integers(33, 300), 32 * rng.integers(2, 8), 8 * rng.integers(5, 36)]))
+        kw = dict(levels=int(rng.integers(0, 5)), winsize=int(rng.choice([3, 5, 7, 8, 11, 15, 15, 15, 21, 25])),
+                  iterations=int(rng.integers(1, 4)), poly_n=int(rng.choice([3, 5, 5, 5, 7])),
+                  poly_sigma=float(rng.choice([1.1, 1.2, 1.5])), pyr_scale=float(rng.choice([0.5, 0.5, 0.5, 0.6, 0.8])),
+                  flags=int(rng.choice([0, 0, 0, 4, 256, 260])))
+        out.append((w, h, 9000 + i, kw))
+    return out
+
+
+@pytest.mark.parametrize("w,h,seed,kw", _fuzz_cases(36, 20261004))
+def test_fuzz_pipeline_bit_exact(H, oracle, w, h, seed, kw, monkeypatch):
+    """Random sizes and parameter sets (fused, generic, direct-level and flag paths all get hit): the whole pipeline
+    bit for bit against the oracle in the device summation order."""
+    monkeypatch.setenv("OFARN_DIRECT_MIN_FRAMES", "1" if seed % 2 else "32")
+    a, b, (tx, ty) = translated_pair(h, w, seed, max_shift=4)
+    init = None
+    if kw["flags"] & 4:
+        init = np.empty((h, w, 2), np.float32)
+        init[...] = (tx + 0.25, ty - 0.5)
+    ref = oracle.farneback(a, b, box_mode=oracle.BOX_BLOCKED, init_flow=init, **kw)
+    with H.FarnebackEngine(w, h, 1, **kw) as eng:
+        got = eng.calc(a, b, None if init is None else init.copy())
+    np.testing.assert_array_equal(got, ref)
