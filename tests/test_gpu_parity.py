@@ -718,3 +718,30 @@ def test_fuzz_pipeline_bit_exact(H, oracle, w, h, seed, kw, monkeypatch):
     with H.FarnebackEngine(w, h, 1, **kw) as eng:
         got = eng.calc(a, b, None if init is None else init.copy())
     np.testing.assert_array_equal(got, ref)
+
+
+def _lk_fuzz_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        w, h = int(rng.integers(40, 400)), int(rng.integers(40, 300))
+        win = (int(rng.integers(3, 50)), int(rng.integers(3, 50)))
+        kw = dict(winSize=win, maxLevel=int(rng.integers(0, 5)),
+                  criteria=(int(rng.choice([1, 2, 3])), int(rng.integers(1, 25)), float(rng.choice([0.001, 0.01, 0.03, 0.3]))),
+                  flags=int(rng.choice([0, 0, 0, 8])), minEigThreshold=float(rng.choice([1e-4, 1e-3, 1e-6])))
+        out.append((w, h, 9500 + i, kw))
+    return out
+
+
+@pytest.mark.parametrize("w,h,seed,kw", _lk_fuzz_cases(24, 7))
+def test_fuzz_lk_bit_exact(H, oracle, w, h, seed, kw):
+    a, b, _ = translated_pair(h, w, seed, max_shift=4)
+    pts = np.random.default_rng(seed).uniform((-8, -8), (w + 8, h + 8), (120, 2)).astype(np.float32)
+    got_n, got_s, got_e = H.calcOpticalFlowPyrLK(a, b, pts, None, **kw)
+    okw = dict(kw)
+    ctype, cnt, eps = okw.pop("criteria")
+    okw["criteria"] = (cnt if ctype & 1 else 30, eps if ctype & 2 else 0.01)
+    ref_n, ref_s, ref_e = oracle.calc_optical_flow_pyr_lk(a, b, pts, None, sum_mode=oracle.LK_SUM_COLUMNS, **okw)
+    np.testing.assert_array_equal(got_s[:, 0], ref_s)
+    np.testing.assert_array_equal(got_n, ref_n)
+    np.testing.assert_array_equal(got_e[:, 0], ref_e)
