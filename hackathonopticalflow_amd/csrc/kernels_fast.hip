@@ -751,6 +751,95 @@ __global__ __launch_bounds__(EDGE ? 64 : 256) void k_level_direct(const uint8_t 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_level_hdirect<S, K>: stage A row pass for a level whose WIDTH is exactly 1/S of the frame's, S = 16, 32, 64
+// (K = 39, 79, 159 taps), straight from the uint8 frame: no LDS staging, no barrier.  One thread per (frame row,
+// level column): the K+1 source bytes of its two sampled columns start at S*x + S/2 - 1 - K/2, which is a multiple
+// of 4 for these (S, K), so they arrive as (K+1)/4 aligned dwords and are unpacked with v_cvt_f32_ubyteN; taps are
+// kernel arguments (SGPRs).  Same arithmetic and order as k_level_hpass*.  EDGE: columns 0 and w-1, whose taps
+// cross the frame border, with reflected byte loads in a second tiny launch.
+// ---------------------------------------------------------------------------------------------
+constexpr int HD_ROWS = 4;
+
+template <int S, int K, bool EDGE>
+__global__ __launch_bounds__(EDGE ? 64 : 128) void k_level_hdirect(const uint8_t *__restrict__ frames, size_t frame_stride, int W,
+                                                                   int H, TapsArg<K> taps, float2 *__restrict__ tmp, int w)
+{
+    constexpr int r = K / 2;
+    static_assert((S / 2 - 1 - r) % 4 == 0 && (K + 1) % 4 == 0, "window must start on a dword and span whole dwords");
+    int x, y;
+    if (EDGE) {
+        x = (threadIdx.x & 1) ? w - 1 : 0;
+        y = blockIdx.y * 32 + (threadIdx.x >> 1);
+        if (w == 1 && (threadIdx.x & 1)) return;
+    } else {
+        x = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+        y = blockIdx.y * HD_ROWS;
+        if (x > w - 2) return;
+    }
+    const int cl = S * x + S / 2 - 1 - r;
+    // interior threads take HD_ROWS consecutive frame rows each (fewer, longer blocks; the next row's loads overlap this row's sums)
+    for (int rr = 0; rr < (EDGE ? 1 : HD_ROWS); rr++, y++) {
+    if (y >= H) return;
+    const uint8_t *row = frames + (size_t)blockIdx.z * frame_stride + (size_t)y * W;
+    float a0 = 0.f, a1 = 0.f;
+    if (EDGE) {
+        float prev = (float)row[reflect101_once(cl, W)];
+        a0 = taps.k[0] * prev;
+#pragma unroll 8
+        for (int t = 1; t <= K; t++) {
+            const float v = (float)row[reflect101_once(cl + t, W)];
+            if (t < K) a0 = a0 + taps.k[t] * v;
+            a1 = t == 1 ? taps.k[0] * v : a1 + taps.k[t - 1] * v;
+        }
+    } else {
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(row + cl);
+        uint32_t d[(K + 1) / 4];
+#pragma unroll
+        for (int i = 0; i < (K + 1) / 4; i++) d[i] = q[i];
+#pragma unroll
+        for (int t = 0; t <= K; t++) {
+            const float v = (float)((d[t / 4] >> (8 * (t % 4))) & 255u);
+            if (t == 0) a0 = taps.k[0] * v;
+            else if (t < K) a0 = a0 + taps.k[t] * v;
+            if (t == 1) a1 = taps.k[0] * v;
+            else if (t > 1) a1 = a1 + taps.k[t - 1] * v;
+        }
+    }
+    tmp[((size_t)blockIdx.z * H + y) * w + x] = make_float2(a0, a1);
+    }
+}
+
+bool level_hdirect_supported(const void *frames, int W, int w, int ksize)
+{
+    if (w < 2 || ((uintptr_t)frames & 3) || (W & 3)) return false;
+    return (W == 16 * w && ksize == 39) || (W == 32 * w && ksize == 79) || (W == 64 * w && ksize == 159);
+}
+
+template <int S, int K>
+static void launch_level_hdirect_sk(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
+                                    const float *h_kern, float *tmp, int w)
+{
+    TapsArg<K> taps;
+    for (int i = 0; i < K; i++) taps.k[i] = h_kern[i];
+    float2 *t2 = reinterpret_cast<float2 *>(tmp);
+    if (w > 2) {
+        const int nt = w - 2 > 64 ? 128 : 64;
+        dim3 grid((unsigned)((w - 2 + nt - 1) / nt), (unsigned)((H + HD_ROWS - 1) / HD_ROWS), nframes);
+        hipLaunchKernelGGL((k_level_hdirect<S, K, false>), grid, dim3(nt), 0, s, frames, frame_stride, W, H, taps, t2, w);
+    }
+    dim3 egrid(1, (unsigned)((H + 31) / 32), nframes);
+    hipLaunchKernelGGL((k_level_hdirect<S, K, true>), egrid, dim3(64), 0, s, frames, frame_stride, W, H, taps, t2, w);
+}
+
+void launch_level_hdirect(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
+                          const float *h_kern, int ksize, float *tmp, int w)
+{
+    if (W == 16 * w && ksize == 39) launch_level_hdirect_sk<16, 39>(s, frames, frame_stride, W, H, nframes, h_kern, tmp, w);
+    else if (W == 32 * w && ksize == 79) launch_level_hdirect_sk<32, 79>(s, frames, frame_stride, W, H, nframes, h_kern, tmp, w);
+    else if (W == 64 * w && ksize == 159) launch_level_hdirect_sk<64, 159>(s, frames, frame_stride, W, H, nframes, h_kern, tmp, w);
+}
+
 static inline unsigned cdivu(int a, int b) { return (unsigned)((a + b - 1) / b); }
 int best_strip_units(int nunits, int unit, int warm, int blocks_per_strip_row, int blocks_per_cu);
 

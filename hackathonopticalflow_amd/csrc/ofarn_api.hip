@@ -446,6 +446,7 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
     // tmp buffers fit side by side in the workspace; tmp_of[k] is where level k's rows went.
     const bool march0 = !c->force_generic && polyexp_march_supported(c->prm.poly_n);
     float *tmp_of[32] = {nullptr};
+    bool hdirect[32] = {false};
     if (!c->force_generic) {
         HLevels HL{};
         size_t off = 0;
@@ -457,16 +458,29 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
                 continue;   // built by k_level_direct, no tmp
             const size_t need = (size_t)nframes * h * L.w * 2;
             if (HL.n >= 12 || off + need > c->tmp_floats) { ok = false; break; }
-            HL.lv[HL.n++] = HLevel{L.d_kern, L.d_xofs, ws.tmp + off, L.w, L.ksize};
-            if (L.ksize / 2 > HL.rmax) HL.rmax = L.ksize / 2;
+            if (nframes >= c->direct_min_frames && level_hdirect_supported(d_frames, w, L.w, L.ksize))
+                hdirect[k] = true;   // 1/16, 1/32, 1/64 widths: row pass straight from the frames, no LDS staging
+            else {
+                HL.lv[HL.n++] = HLevel{L.d_kern, L.d_xofs, ws.tmp + off, L.w, L.ksize};
+                if (L.ksize / 2 > HL.rmax) HL.rmax = L.ksize / 2;
+            }
             tmp_of[k] = ws.tmp + off;
             off += need;
         }
         HL.rmax = (HL.rmax + 3) & ~3;   // border width in LDS: a multiple of 4 keeps the 16-byte staging writes aligned
-        if (ok && HL.n > 0 && hpass_multi_lds_bytes(w, HL.rmax) <= 60 * 1024) {
-            double units = 0;
-            for (int i = 0; i < HL.n; i++) units += (double)HL.lv[i].dw * h * nframes;
-            timed(c, s, OFARN_STAGE_LEVEL_H, 31, units, [&] { launch_level_hpass_multi(s, d_frames, fsz, w, h, nframes, HL); });
+        if (ok && (HL.n == 0 || hpass_multi_lds_bytes(w, HL.rmax) <= 60 * 1024)) {
+            if (HL.n > 0) {
+                double units = 0;
+                for (int i = 0; i < HL.n; i++) units += (double)HL.lv[i].dw * h * nframes;
+                timed(c, s, OFARN_STAGE_LEVEL_H, 31, units, [&] { launch_level_hpass_multi(s, d_frames, fsz, w, h, nframes, HL); });
+            }
+            for (int k = nlev; k >= 0; k--)
+                if (hdirect[k]) {
+                    const Level &L = c->lv[k];
+                    timed(c, s, OFARN_STAGE_LEVEL_H, k, (double)L.w * h * nframes, [&] {
+                        launch_level_hdirect(s, d_frames, fsz, w, h, nframes, L.h_kern.data(), L.ksize, tmp_of[k], L.w);
+                    });
+                }
         } else
             for (auto &t : tmp_of) t = nullptr;
     }
@@ -1457,7 +1471,9 @@ int ofarn_stage_level_image(ofarn_ctx *c, const uint8_t *h_img, int w, int h, in
     if (!c->force_generic && level_direct_supported(c->st_frames, w, h, L.w, L.h, L.ksize))
         launch_level_direct(c->stream, c->st_frames, fsz, w, h, 1, L.h_kern.data(), L.ksize, c->ws[0].I, L.w, L.h);
     else {
-        if (!c->force_generic && lds_ok)
+        if (!c->force_generic && level_hdirect_supported(c->st_frames, w, L.w, L.ksize))
+            launch_level_hdirect(c->stream, c->st_frames, fsz, w, h, 1, L.h_kern.data(), L.ksize, c->ws[0].tmp, L.w);
+        else if (!c->force_generic && lds_ok)
             launch_level_hpass_lds(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->ws[0].tmp);
         else
             launch_level_hpass(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->ws[0].tmp);

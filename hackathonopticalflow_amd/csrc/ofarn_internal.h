@@ -90,6 +90,11 @@ void launch_level_hpass_multi(hipStream_t s, const uint8_t *frames, size_t frame
 bool level_direct_supported(const void *frames, int W, int H, int w, int h, int ksize);
 void launch_level_direct(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
                          const float *h_kern, int ksize, float *I, int w, int h);
+// Stage A row pass straight from the frames for levels whose width is exactly 1/16, 1/32 or 1/64 of the frame's
+// (kernels_fast.hip): fills the same tmp layout as the other row passes.  h_kern: host pointer to the ksize taps.
+bool level_hdirect_supported(const void *frames, int W, int w, int ksize);
+void launch_level_hdirect(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
+                          const float *h_kern, int ksize, float *tmp, int w);
 // Stage F: grid sample + vector filter + danger brightness.  d_pts int2[P] grid coordinates.
 int grid_filter_lds_bytes(int P);
 void launch_grid_filter(hipStream_t s, const float *flow, int w, int h, int npairs, const int *d_pts,
