@@ -135,6 +135,8 @@ def main():
                     help="torch.distributed backend for N > 1 (gloo: rehearsal of the multi-rank path with "
                          "several ranks sharing one GPU; the gather then goes through host memory)")
     args = ap.parse_args()
+    if args.steps < 1 or args.warmup < 0 or args.batch < 1 or args.wave < 1:
+        raise SystemExit("--steps and --batch and --wave must be >= 1, --warmup >= 0")
 
     import torch
     import hackathonopticalflow_amd as ofa
