@@ -63,6 +63,7 @@ void launch_scharr(hipStream_t s, const uint8_t *src, int w, int h, int16_t *dst
 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lk_descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
+constexpr int LK_CHUNK = 15;   // window rows whose loads are in flight together (45 = 3 x 15)
 
 // float sum over the window columns in lane order (every lane computes the same value from LDS)
 __device__ __forceinline__ float lk_colsum(const float *red, int ww)
@@ -139,24 +140,28 @@ __global__ __launch_bounds__(64) void k_lk_track(LkLevelArgs A)
             d0 = (yin && in0) ? dI[(size_t)Y * cols + X0] : make_short2(0, 0);
             d1 = (yin && in1) ? dI[(size_t)Y * cols + X1] : make_short2(0, 0);
         };
-        int t0, t1;
-        short2 e0, e1;
-        pix(ipy, t0, t1);
-        der(ipy, e0, e1);
-        for (int y = 0; y < wh; y++) {
-            int u0, u1;
-            short2 f0, f1;
-            pix(ipy + y + 1, u0, u1);
-            der(ipy + y + 1, f0, f1);
-            const int ival = lk_descale(t0 * iw00 + t1 * iw01 + u0 * iw10 + u1 * iw11, 9);
-            const int ixval = lk_descale(e0.x * iw00 + e1.x * iw01 + f0.x * iw10 + f1.x * iw11, 14);
-            const int iyval = lk_descale(e0.y * iw00 + e1.y * iw01 + f0.y * iw10 + f1.y * iw11, 14);
-            sI[y * ww + lane] = (short)ival;
-            sD[y * ww + lane] = make_short2((short)ixval, (short)iyval);
-            a11 += (float)(ixval * ixval);
-            a12 += (float)(ixval * iyval);
-            a22 += (float)(iyval * iyval);
-            t0 = u0; t1 = u1; e0 = f0; e1 = f1;
+        for (int yb = 0; yb < wh; yb += LK_CHUNK) {
+            int p0[LK_CHUNK + 1], p1[LK_CHUNK + 1];
+            short2 q0[LK_CHUNK + 1], q1[LK_CHUNK + 1];
+#pragma unroll
+            for (int i = 0; i <= LK_CHUNK; i++) {
+                pix(ipy + yb + i, p0[i], p1[i]);
+                der(ipy + yb + i, q0[i], q1[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < LK_CHUNK; i++) {
+                const int y = yb + i;
+                if (y < wh) {
+                    const int ival = lk_descale(p0[i] * iw00 + p1[i] * iw01 + p0[i + 1] * iw10 + p1[i + 1] * iw11, 9);
+                    const int ixval = lk_descale(q0[i].x * iw00 + q1[i].x * iw01 + q0[i + 1].x * iw10 + q1[i + 1].x * iw11, 14);
+                    const int iyval = lk_descale(q0[i].y * iw00 + q1[i].y * iw01 + q0[i + 1].y * iw10 + q1[i + 1].y * iw11, 14);
+                    sI[y * ww + lane] = (short)ival;
+                    sD[y * ww + lane] = make_short2((short)ixval, (short)iyval);
+                    a11 += (float)(ixval * ixval);
+                    a12 += (float)(ixval * iyval);
+                    a22 += (float)(iyval * iyval);
+                }
+            }
         }
     }
     red[lane] = a11; red[64 + lane] = a12; red[128 + lane] = a22;
@@ -184,19 +189,29 @@ __global__ __launch_bounds__(64) void k_lk_track(LkLevelArgs A)
         float s1 = 0.f, s2 = 0.f;
         if (act) {
             const int cx0 = reflect101(inx + lane, cols), cx1 = reflect101(inx + lane + 1, cols);
-            const uint8_t *r = J + (size_t)reflect101(iny, rows) * cols;
-            int t0 = r[cx0], t1 = r[cx1];
-            for (int y = 0; y < wh; y++) {
-                r = J + (size_t)reflect101(iny + y + 1, rows) * cols;
-                const int u0 = r[cx0], u1 = r[cx1];
-                const int diff = lk_descale(t0 * w00 + t1 * w01 + u0 * w10 + u1 * w11, 9) - (int)sI[y * ww + lane];
-                if (mode == 0) {
-                    const short2 d = sD[y * ww + lane];
-                    s1 += (float)(diff * (int)d.x);
-                    s2 += (float)(diff * (int)d.y);
-                } else
-                    s1 += fabsf((float)diff);
-                t0 = u0; t1 = u1;
+            // rows in chunks of LK_CHUNK: all the byte loads of a chunk are issued before its arithmetic, so a pass pays a
+            // few memory round trips instead of one per window row
+            for (int yb = 0; yb < wh; yb += LK_CHUNK) {
+                int v0[LK_CHUNK + 1], v1[LK_CHUNK + 1];
+#pragma unroll
+                for (int i = 0; i <= LK_CHUNK; i++) {
+                    const uint8_t *r = J + (size_t)reflect101(iny + yb + i, rows) * cols;
+                    v0[i] = r[cx0];
+                    v1[i] = r[cx1];
+                }
+#pragma unroll
+                for (int i = 0; i < LK_CHUNK; i++) {
+                    const int y = yb + i;
+                    if (y < wh) {
+                        const int diff = lk_descale(v0[i] * w00 + v1[i] * w01 + v0[i + 1] * w10 + v1[i + 1] * w11, 9) - (int)sI[y * ww + lane];
+                        if (mode == 0) {
+                            const short2 d = sD[y * ww + lane];
+                            s1 += (float)(diff * (int)d.x);
+                            s2 += (float)(diff * (int)d.y);
+                        } else
+                            s1 += fabsf((float)diff);
+                    }
+                }
             }
         }
         red[lane] = s1; red[64 + lane] = s2;

@@ -351,7 +351,8 @@ class FarnebackEngine:
                           d_flow=None, d_mask=None, d_v=None, stream=None, bgr=False):
         """Device-resident batch: arguments are torch CUDA tensors (or raw device addresses).
         Enqueues on `stream` (raw hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream;
-        None = the engine's own stream) and does not synchronise.  bgr=True: d_frames are decoded video
+        None = the engine's own stream, which is NOT ordered with torch's: tensors produced by pending torch
+        kernels must be synchronised first) and does not synchronise.  bgr=True: d_frames are decoded video
         frames uint8[n_frames,H,W,3] and cv2.cvtColor(COLOR_BGR2GRAY) (DenseOF.py:510) runs on the device
         in front of the flow.  With OPTFLOW_USE_INITIAL_FLOW d_flow holds the initial flows on entry."""
         fn = self._lib.ofarn_calc_batch_device_bgr if bgr else self._lib.ofarn_calc_batch_device

@@ -476,7 +476,8 @@ def test_use_initial_flow_batch(H, oracle):
         for i in range(n_pairs):
             np.testing.assert_array_equal(flow[i], ref[i])
         d_flow = torch.from_numpy(init).cuda()                      # in/out on the device, several waves
-        eng.calc_batch_device(torch.from_numpy(frames).cuda(), 2 * n_pairs, w, h, H.PAIRS_INDEPENDENT, d_flow, None, None)
+        eng.calc_batch_device(torch.from_numpy(frames).cuda(), 2 * n_pairs, w, h, H.PAIRS_INDEPENDENT, d_flow, None, None,
+                              stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         np.testing.assert_array_equal(d_flow.cpu().numpy(), np.stack(ref))
         with pytest.raises(ValueError):
@@ -612,11 +613,12 @@ def test_lk_batch_device_and_get_flow_lk(H, oracle):
             d_next = torch.zeros((n_pairs, P, 2), dtype=torch.float32, device="cuda")
             d_st = torch.zeros((n_pairs, P), dtype=torch.uint8, device="cuda")
             d_err = torch.zeros((n_pairs, P), dtype=torch.float32, device="cuda")
+            st = torch.cuda.current_stream().cuda_stream      # one stream for the library and for torch's own kernels
             eng.lk_batch_device(d_frames, n_frames if mode == H.PAIRS_CONSECUTIVE else 2 * n_pairs, w, h, mode, d_pts, P,
-                                d_next, d_st, d_err, reverse=True, **lk)
+                                d_next, d_st, d_err, reverse=True, stream=st, **lk)
             d_mask = torch.zeros((n_pairs, P), dtype=torch.uint8, device="cuda")
             d_v = torch.zeros_like(d_mask)
-            eng.vector_filter_device(d_next - d_pts, n_pairs, w, h, d_mask, d_v)
+            eng.vector_filter_device(d_next - d_pts, n_pairs, w, h, d_mask, d_v, stream=st)
             torch.cuda.synchronize()
             for i in range(n_pairs):
                 f1, f2 = (frames[i], frames[i + 1]) if mode == H.PAIRS_CONSECUTIVE else (frames[2 * i], frames[2 * i + 1])
@@ -679,7 +681,8 @@ def test_lk_batch_points_per_pair_and_forward_direction(H, oracle):
     d_err = torch.zeros((n_pairs, npts), dtype=torch.float32, device="cuda")
     with H.FarnebackEngine(w, h, 2) as eng:
         eng.lk_batch_device(torch.from_numpy(frames).cuda(), 2 * n_pairs, w, h, H.PAIRS_INDEPENDENT, torch.from_numpy(pts).cuda(),
-                            npts, d_next, d_st, d_err, reverse=False, pts_per_pair=True, winSize=(21, 21), maxLevel=2)
+                            npts, d_next, d_st, d_err, reverse=False, pts_per_pair=True,
+                            stream=torch.cuda.current_stream().cuda_stream, winSize=(21, 21), maxLevel=2)
         torch.cuda.synchronize()
     for i in range(n_pairs):
         ref_n, ref_s, ref_e = oracle.calc_optical_flow_pyr_lk(frames[2 * i], frames[2 * i + 1], pts[i], None, winSize=(21, 21),
