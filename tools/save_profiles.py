@@ -31,8 +31,8 @@ with open("profiles/r01_kernel_stats_by_grid.csv", "w") as o:
     o.write("# Derived from the kernel trace of the same rocprofv3 --kernel-trace --stats run as r01_kernel_stats.csv.\n"
             "# Split per kernel, grid (= pyramid level) and stream.  bench.py measures roofline.kernel_avg_ms with HIP events over its timed\n"
             "# region, in which per-kernel profiling keeps all waves on ONE stream (kernels do not overlap): compare with the rows of the\n"
-            "# stream that carries most launches.  The warm-up steps run unprofiled on two internal streams, where kernels of two waves\n"
-            "# overlap and each one's duration is about doubled (those rows are marked by their stream id as well).\n")
+            "# stream 1 (the caller's).  The warm-up steps and the informational `two_stream_pairs_per_s` phase run with per-kernel timing\n"
+            "# off on two internal streams (ids 2 and 3), where kernels of two waves overlap and each one's duration is about doubled.\n")
     o.write("kernel,grid_x,grid_y,grid_z,stream_id,calls,avg_ns,total_ns\n")
     for k in sorted(acc, key=lambda k: -sum(acc[k])):
         v = acc[k]
