@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=16, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel hipEvent timing")
     ap.add_argument("--prof-table", action="store_true", help="print per-(stage, level) timing rows to stderr")
+    ap.add_argument("--no-two-stream", action="store_true",
+                    help="skip the informational second measurement with per-kernel timing off (two internal streams)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (gloo: rehearsal of the multi-rank path with "
                          "several ranks sharing one GPU; the gather then goes through host memory)")
@@ -205,7 +207,7 @@ def main():
     # iterations of the other; per-kernel durations lose their meaning there, which is why the timed region above keeps
     # everything on one stream.
     overlapped = None
-    if not args.no_profile and min(args.wave, B) < B:
+    if not args.no_profile and not args.no_two_stream and min(args.wave, B) < B:
         step()
         fence()
         t0 = time.perf_counter()

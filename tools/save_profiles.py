@@ -13,7 +13,7 @@ open("profiles/r01_bench_final_stage_table.txt", "w").write(
     "".join(l for l in open(bench_err) if "amdgpu.ids" not in l))
 rows = list(csv.DictReader(open(prof_dir + "/runc_kernel_stats.csv")))
 with open("profiles/r01_kernel_stats.csv", "w") as o:
-    o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 (MI355X, final round-1 build); ofarn kernels only\n")
+    o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-two-stream (MI355X, final round-1 build); ofarn kernels only\n")
     w = csv.DictWriter(o, fieldnames=rows[0].keys())
     w.writeheader()
     for r in rows:
@@ -31,8 +31,8 @@ with open("profiles/r01_kernel_stats_by_grid.csv", "w") as o:
     o.write("# Derived from the kernel trace of the same rocprofv3 --kernel-trace --stats run as r01_kernel_stats.csv.\n"
             "# Split per kernel, grid (= pyramid level) and stream.  bench.py measures roofline.kernel_avg_ms with HIP events over its timed\n"
             "# region, in which per-kernel profiling keeps all waves on ONE stream (kernels do not overlap): compare with the rows of the\n"
-            "# stream 1 (the caller's).  The warm-up steps and the informational `two_stream_pairs_per_s` phase run with per-kernel timing\n"
-            "# off on two internal streams (ids 2 and 3), where kernels of two waves overlap and each one's duration is about doubled.\n")
+            "# stream 1 (the caller's).  The warm-up step runs with per-kernel timing off on two internal streams (ids 2 and 3), where\n"
+            "# kernels of two waves overlap and each one's duration is about doubled.\n")
     o.write("kernel,grid_x,grid_y,grid_z,stream_id,calls,avg_ns,total_ns\n")
     for k in sorted(acc, key=lambda k: -sum(acc[k])):
         v = acc[k]
