@@ -1,25 +1,18 @@
-// ofarn_api.hip -- host side of libofarn.so: the C-ABI of include/ofarn.h.
+// ofarn_api.hip -- host side of libofarn.so: the core of the C-ABI of include/ofarn.h (context, plan, the dense
+// Farneback wave schedule, batch entry points, grid filter).  The front end / visualiser / single-stage entry points
+// are in ofarn_api_extras.hip, sparse LK in ofarn_api_lk.hip; shared internals in ofarn_host.h.
 //
 // Owns the HBM workspace, the per-frame-size level plan (optflowgf.cpp calc(): level sizes,
 // Gaussian kernels, resize tables) and the per-level launch schedule
 //     A (level image) -> B (poly expansion) -> E (flow upsample) -> C, [D, C] x (I-1), D
 // for a wave of frame pairs at a time.  No oracle or CPU fallback exists on this path: if a HIP
 // call fails the entry point returns OFARN_E_HIP.
-#include "../../include/ofarn.h"
-#include "ofarn_internal.h"
-
-#include <cfloat>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
+#include "ofarn_host.h"
 
 using namespace ofarn;
+using namespace ofarn_host;
 
-namespace {
+namespace ofarn_host {
 
 thread_local std::string g_err;
 
@@ -34,29 +27,6 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
-#define HIP_TRY(expr)                                                                         \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess)                                                                 \
-            return fail(OFARN_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
-                        __FILE__, __LINE__);                                                  \
-    } while (0)
-
-// device scratch that lives for one host-pointer call
-struct DevTmp {
-    void *p = nullptr;
-    ~DevTmp() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes)
-    {
-        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
-            (void)hipGetLastError();
-            p = nullptr;
-            return fail(OFARN_E_NOMEM, "device scratch of %zu bytes does not fit", bytes);
-        }
-        return OFARN_OK;
-    }
-    template <typename T> T *as() { return static_cast<T *>(p); }
-};
 
 inline int cv_round(double v) { return (int)lrint(v); }   // cvRound: half to even
 inline int cv_floor(float v) { int i = (int)v; return i - (i > v); }
@@ -180,18 +150,6 @@ void area_axis(int ssize, int dsize, double scale, AreaAxis &t)
     }
 }
 
-struct Level {
-    int w = 0, h = 0, ksize = 0;
-    double sigma = 0;
-    // device tables
-    float *d_kern = nullptr;
-    float h_kern3[3] = {0, 0, 0};   // host copy of the taps when ksize == 3
-    std::vector<float> h_kern;      // host copy of all taps (passed by value to k_level_direct)
-    int *d_xofs = nullptr, *d_yofs = nullptr;        // image resize W->w, H->h
-    float *d_xa = nullptr, *d_ya = nullptr;
-    int *d_fxofs = nullptr, *d_fyofs = nullptr;      // flow resize (k+1) -> k
-    float *d_fxa = nullptr, *d_fya = nullptr;
-};
 
 int axis_points(int size, int step, std::vector<int> *out)
 {
@@ -249,61 +207,10 @@ int check_params(const ofarn_params *p)
     return OFARN_OK;
 }
 
-}  // namespace
+}  // namespace ofarn_host
 
-struct ofarn_ctx {
-    ofarn_params prm{};
-    int device = 0;
-    int max_w = 0, max_h = 0, max_batch = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    PolyCoef poly{};
-    float *d_gwin = nullptr;     // m+1 taps of the OPTFLOW_FARNEBACK_GAUSSIAN window
-    // plan (cached for one frame size)
-    int plan_w = 0, plan_h = 0;
-    std::vector<Level> lv;
-    int *d_pts = nullptr;
-    int P = 0;
-    AreaTabHost area;            // resize(INTER_AREA) full size -> coarsest level (OPTFLOW_USE_INITIAL_FLOW)
-    float init_scale = 1.f;      // pyr_scale ^ levels, as optflowgf.cpp accumulates it
-    std::vector<void *> plan_allocs;
-    // workspace
-    // two workspaces: waves of one batch alternate between them on two internal streams, so the tail
-    // of one wave's kernels overlaps the other wave's (the second is allocated on first use)
-    struct Workspace { float *tmp = nullptr, *I = nullptr, *R = nullptr, *M = nullptr, *flowA = nullptr, *flowB = nullptr; };
-    Workspace ws[2];
-    hipStream_t aux[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
-    bool dual = true;            // OFARN_SINGLE_STREAM=1 disables the second workspace
-    uint64_t ws_bytes = 0;
-    size_t tmp_floats = 0;   // capacity of tmp in floats
-    uint8_t *gray[2] = {nullptr, nullptr};   // gray frames of a wave when the caller hands over BGR (lazy)
-    // sparse LK (lazy): pyramid levels >= 1 (uint8) and Scharr derivatives of every level (int16 x 2) for one wave of frames
-    struct LkWs {
-        int w = 0, h = 0, frames = 0, levels = -1;
-        std::vector<int> lw, lh;
-        std::vector<uint8_t *> pyr;      // pyr[0] unused (level 0 is the caller's frames)
-        std::vector<int16_t *> der;
-    } lk;
-    // host-API staging (lazy)
-    uint8_t *st_frames = nullptr;
-    float *st_flow = nullptr;
-    uint8_t *st_mask = nullptr, *st_v = nullptr;
-    size_t st_frames_cap = 0, st_flow_cap = 0, st_dm_cap = 0;
-    double last_ms = 0;
-    // per-kernel profiling (ofarn_profile_*): hipEvent pairs around each launch, on the launch stream
-    struct ProfRec { int stage, level; double units; hipEvent_t a, b; };
-    bool prof_on = false;
-    bool force_generic = false;   // OFARN_FORCE_GENERIC=1 or ofarn_set_option: use the unfused kernels only
-    int direct_min_frames = 32;   // k_level_direct marches long strips per thread: below this many frames in a wave the
-                                  // row-pass + column-pass pair has more parallelism and lower latency (OFARN_DIRECT_MIN_FRAMES)
-    std::vector<ProfRec> prof_pending;
-    std::vector<hipEvent_t> prof_free;
-    struct ProfAcc { int launches = 0; double ms = 0, units = 0; };
-    ProfAcc prof_acc[OFARN_STAGE_COUNT][32];
-};
 
-namespace {
+namespace ofarn_host {
 
 void free_plan(ofarn_ctx *c)
 {
@@ -416,17 +323,6 @@ hipEvent_t prof_event(ofarn_ctx *c)
     return e;
 }
 
-// Runs `launch` and, when profiling is on, brackets it with two events on the same stream.
-template <typename F>
-inline void timed(ofarn_ctx *c, hipStream_t s, int stage, int level, double units, F &&launch)
-{
-    if (!c->prof_on) { launch(); return; }
-    ofarn_ctx::ProfRec r{stage, level, units, prof_event(c), prof_event(c)};
-    (void)hipEventRecord(r.a, s);
-    launch();
-    (void)hipEventRecord(r.b, s);
-    c->prof_pending.push_back(r);
-}
 
 // One wave: npairs <= max_batch pairs, frames already in HBM.
 // d_init (OPTFLOW_USE_INITIAL_FLOW): full-resolution start flows float[npairs][h][w][2]; may alias d_flow.
@@ -654,9 +550,10 @@ int alloc_workspace(ofarn_ctx *c, int wi)
     return 0;
 }
 
-}  // namespace
+}  // namespace ofarn_host
 
 extern "C" {
+#pragma GCC visibility push(default)
 
 void ofarn_default_params(ofarn_params *p)
 {
@@ -833,9 +730,10 @@ int ofarn_grid_points(int w, int h, int step, float *h_pts)
     return (int)(xs.size() * ys.size());
 }
 
+#pragma GCC visibility pop
 }  // extern "C"
 
-namespace {
+namespace ofarn_host {
 
 // gray staging for BGR input: 2 * max_batch frames per workspace
 int ensure_gray(ofarn_ctx *c, int wi)
@@ -850,8 +748,6 @@ int ensure_gray(ofarn_ctx *c, int wi)
     return OFARN_OK;
 }
 
-// cv2.cvtColor(COLOR_BGR2GRAY) coefficients: color_rgb.simd.hpp RGB2Gray<uchar>, 15-bit fixed point (B, G, R)
-constexpr int kGrayB = 3735, kGrayG = 19235, kGrayR = 9798, kGrayShift = 15;
 
 int calc_batch_device_impl(ofarn_ctx *c, const uint8_t *d_frames, bool bgr, int n_frames, int w, int h, int pairs_mode,
                            float *d_flow, uint8_t *d_mask, uint8_t *d_v, void *hip_stream)
@@ -910,17 +806,11 @@ int calc_batch_device_impl(ofarn_ctx *c, const uint8_t *d_frames, bool bgr, int 
     return OFARN_OK;
 }
 
-// np.mgrid[step/2:size:step] (DenseOF.py:44): count and float start
-int arrow_axis(int size, int step, double *start)
-{
-    *start = step / 2.0;
-    const int n = (int)std::ceil((size - *start) / (step * 1.0));
-    return n < 0 ? 0 : n;
-}
 
-}  // namespace
+}  // namespace ofarn_host
 
 extern "C" {
+#pragma GCC visibility push(default)
 
 int ofarn_calc_batch_device(ofarn_ctx *c, const uint8_t *d_frames, int n_frames, int w, int h, int pairs_mode,
                             float *d_flow, uint8_t *d_mask, uint8_t *d_v, void *hip_stream)
@@ -932,161 +822,6 @@ int ofarn_calc_batch_device_bgr(ofarn_ctx *c, const uint8_t *d_bgr, int n_frames
                                 float *d_flow, uint8_t *d_mask, uint8_t *d_v, void *hip_stream)
 {
     return calc_batch_device_impl(c, d_bgr, true, n_frames, w, h, pairs_mode, d_flow, d_mask, d_v, hip_stream);
-}
-
-int ofarn_bgr2gray_device(ofarn_ctx *c, const uint8_t *d_bgr, int n, int w, int h, uint8_t *d_gray, void *hip_stream)
-{
-    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
-    if (!d_bgr || !d_gray) return fail(OFARN_E_INVALID, "bgr and gray must not be NULL");
-    if (n < 0 || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad size n=%d %dx%d", n, w, h);
-    HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
-    launch_bgr2gray(s, d_bgr, d_gray, (size_t)n * w * h, kGrayB, kGrayG, kGrayR, kGrayShift);
-    HIP_TRY(hipGetLastError());
-    return OFARN_OK;
-}
-
-int ofarn_bgr2gray(ofarn_ctx *c, const uint8_t *h_bgr, int n, int w, int h, int stride, uint8_t *h_gray)
-{
-    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
-    if (!h_bgr || !h_gray) return fail(OFARN_E_INVALID, "bgr and gray must not be NULL");
-    if (n < 0 || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad size n=%d %dx%d", n, w, h);
-    if (stride < 3 * w) return fail(OFARN_E_INVALID, "stride %d < 3 * width %d", stride, w);
-    if (n == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    const size_t npx = (size_t)w * h;
-    DevTmp in, out;
-    int rc;
-    if ((rc = in.alloc(npx * 3)) || (rc = out.alloc(npx))) return rc;
-    for (int i = 0; i < n; i++) {
-        HIP_TRY(hipMemcpy2DAsync(in.p, (size_t)w * 3, h_bgr + (size_t)i * stride * h, stride, (size_t)w * 3, h,
-                                 hipMemcpyHostToDevice, c->stream));
-        launch_bgr2gray(c->stream, in.as<uint8_t>(), out.as<uint8_t>(), npx, kGrayB, kGrayG, kGrayR, kGrayShift);
-        HIP_TRY(hipMemcpyAsync(h_gray + (size_t)i * npx, out.p, npx, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
-    return OFARN_OK;
-}
-
-int ofarn_flow_hsv_device(ofarn_ctx *c, const float *d_flow, int n, int w, int h, uint8_t *d_hsv, uint8_t *d_bgr, void *hip_stream)
-{
-    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
-    if (!d_flow || (!d_hsv && !d_bgr)) return fail(OFARN_E_INVALID, "flow and at least one of hsv, bgr must not be NULL");
-    if (n < 0 || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad size n=%d %dx%d", n, w, h);
-    HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
-    launch_flow_hsv(s, d_flow, (size_t)n * w * h, d_hsv, d_bgr);
-    HIP_TRY(hipGetLastError());
-    return OFARN_OK;
-}
-
-int ofarn_flow_hsv(ofarn_ctx *c, const float *h_flow, int n, int w, int h, uint8_t *h_hsv, uint8_t *h_bgr)
-{
-    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
-    if (!h_flow || (!h_hsv && !h_bgr)) return fail(OFARN_E_INVALID, "flow and at least one of hsv, bgr must not be NULL");
-    if (n < 0 || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad size n=%d %dx%d", n, w, h);
-    if (n == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    const size_t npx = (size_t)w * h;
-    DevTmp in, o1, o2;
-    int rc;
-    if ((rc = in.alloc(npx * 8)) || (rc = o1.alloc(npx * 3)) || (rc = o2.alloc(npx * 3))) return rc;
-    for (int i = 0; i < n; i++) {
-        HIP_TRY(hipMemcpyAsync(in.p, h_flow + (size_t)i * npx * 2, npx * 8, hipMemcpyHostToDevice, c->stream));
-        launch_flow_hsv(c->stream, in.as<float>(), npx, h_hsv ? o1.as<uint8_t>() : nullptr, h_bgr ? o2.as<uint8_t>() : nullptr);
-        if (h_hsv) HIP_TRY(hipMemcpyAsync(h_hsv + (size_t)i * npx * 3, o1.p, npx * 3, hipMemcpyDeviceToHost, c->stream));
-        if (h_bgr) HIP_TRY(hipMemcpyAsync(h_bgr + (size_t)i * npx * 3, o2.p, npx * 3, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
-    return OFARN_OK;
-}
-
-int ofarn_hsv2bgr(ofarn_ctx *c, const uint8_t *h_hsv, size_t npx, uint8_t *h_bgr)
-{
-    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
-    if (!h_hsv || !h_bgr) return fail(OFARN_E_INVALID, "hsv and bgr must not be NULL");
-    if (npx == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    DevTmp in, out;
-    int rc;
-    if ((rc = in.alloc(npx * 3)) || (rc = out.alloc(npx * 3))) return rc;
-    HIP_TRY(hipMemcpyAsync(in.p, h_hsv, npx * 3, hipMemcpyHostToDevice, c->stream));
-    launch_hsv2bgr(c->stream, in.as<uint8_t>(), npx, out.as<uint8_t>());
-    HIP_TRY(hipMemcpyAsync(h_bgr, out.p, npx * 3, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return OFARN_OK;
-}
-
-int ofarn_flow_arrow_count(int w, int h, int step, int *nx, int *ny)
-{
-    if (w < 1 || h < 1 || step < 1) return fail(OFARN_E_INVALID, "bad arrow grid arguments");
-    double st;
-    const int ax = arrow_axis(w, step, &st), ay = arrow_axis(h, step, &st);
-    if (nx) *nx = ax;
-    if (ny) *ny = ay;
-    return ax * ay;
-}
-
-int ofarn_flow_arrows_device(ofarn_ctx *c, const float *d_flow, int n, int w, int h, int step, int32_t *d_lines, void *hip_stream)
-{
-    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
-    if (!d_flow || !d_lines) return fail(OFARN_E_INVALID, "flow and lines must not be NULL");
-    if (n < 0 || w < 1 || h < 1 || step < 1) return fail(OFARN_E_INVALID, "bad arguments n=%d %dx%d step=%d", n, w, h, step);
-    HIP_TRY(hipSetDevice(c->device));
-    double st;
-    const int nx = arrow_axis(w, step, &st), ny = arrow_axis(h, step, &st);
-    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
-    launch_flow_arrows(s, d_flow, w, h, n, nx, ny, st, (double)step, d_lines);
-    HIP_TRY(hipGetLastError());
-    return OFARN_OK;
-}
-
-int ofarn_flow_arrows(ofarn_ctx *c, const float *h_flow, int n, int w, int h, int step, int32_t *h_lines)
-{
-    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
-    if (!h_flow || !h_lines) return fail(OFARN_E_INVALID, "flow and lines must not be NULL");
-    if (n < 0 || w < 1 || h < 1 || step < 1) return fail(OFARN_E_INVALID, "bad arguments n=%d %dx%d step=%d", n, w, h, step);
-    if (n == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    double st;
-    const int nx = arrow_axis(w, step, &st), ny = arrow_axis(h, step, &st);
-    const size_t npx = (size_t)w * h, K = (size_t)nx * ny;
-    if (K == 0) return OFARN_OK;
-    DevTmp in, out;
-    int rc;
-    if ((rc = in.alloc(npx * 8)) || (rc = out.alloc(K * 4 * sizeof(int32_t)))) return rc;
-    for (int i = 0; i < n; i++) {
-        HIP_TRY(hipMemcpyAsync(in.p, h_flow + (size_t)i * npx * 2, npx * 8, hipMemcpyHostToDevice, c->stream));
-        launch_flow_arrows(c->stream, in.as<float>(), w, h, 1, nx, ny, st, (double)step, out.as<int32_t>());
-        HIP_TRY(hipMemcpyAsync(h_lines + (size_t)i * K * 4, out.p, K * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
-    return OFARN_OK;
-}
-
-int ofarn_stage_resize_area(ofarn_ctx *c, const float *h_flow, int sw, int sh, int dw, int dh, float mul, float *h_out)
-{
-    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
-    if (!h_flow || !h_out) return fail(OFARN_E_INVALID, "NULL argument");
-    if (sw < 1 || sh < 1 || dw < 1 || dh < 1) return fail(OFARN_E_INVALID, "bad sizes");
-    HIP_TRY(hipSetDevice(c->device));
-    const size_t saved = c->plan_allocs.size();
-    AreaTabHost t;
-    int rc = build_area_tab(c, sw, sh, dw, dh, t);
-    DevTmp in, out;
-    if (!rc) rc = in.alloc((size_t)sw * sh * 8);
-    if (!rc) rc = out.alloc((size_t)dw * dh * 8);
-    if (!rc) {
-        hipError_t e = hipMemcpyAsync(in.p, h_flow, (size_t)sw * sh * 8, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) {
-            launch_resize_area(c->stream, in.as<float>(), sw, sh, out.as<float>(), dw, dh, 1, t, mul);
-            e = hipMemcpyAsync(h_out, out.p, (size_t)dw * dh * 8, hipMemcpyDeviceToHost, c->stream);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) rc = fail(OFARN_E_HIP, "resize_area stage failed: %s", hipGetErrorString(e));
-    }
-    while (c->plan_allocs.size() > saved) { (void)hipFree(c->plan_allocs.back()); c->plan_allocs.pop_back(); }
-    return rc;
 }
 
 int ofarn_calc_batch(ofarn_ctx *c, const uint8_t *h_frames, int n_frames, int w, int h, int pairs_mode,
@@ -1217,380 +952,8 @@ int ofarn_grid_filter(ofarn_ctx *c, const float *h_flow, int n, int w, int h, ui
     return OFARN_OK;
 }
 
-}  // extern "C"
 
-namespace {
+// (sparse LK entry points: ofarn_api_lk.hip)
 
-int lk_levels(int w, int h, int win_w, int win_h, int max_level)   // buildOpticalFlowPyramid's stop rule
-{
-    int level = 0;
-    while (level < max_level) {
-        const int nw = (w + 1) / 2, nh = (h + 1) / 2;
-        if (nw <= win_w || nh <= win_h) break;
-        w = nw; h = nh; level++;
-    }
-    return level;
-}
-
-int check_lk_params(const ofarn_lk_params *p)
-{
-    if (!p) return fail(OFARN_E_INVALID, "lk params is NULL");
-    if (p->max_level < 0) return fail(OFARN_E_INVALID, "maxLevel must be >= 0, got %d", p->max_level);
-    if (p->win_w <= 2 || p->win_h <= 2) return fail(OFARN_E_INVALID, "winSize must be > 2 (cv2: CV_Assert), got %dx%d", p->win_w, p->win_h);
-    if (p->win_w > 64 || p->win_h > 255) return fail(OFARN_E_UNSUPPORTED, "winSize up to 64 x 255 is built, got %dx%d", p->win_w, p->win_h);
-    if (p->flags & ~(OFARN_LK_USE_INITIAL_FLOW | OFARN_LK_GET_MIN_EIGENVALS))
-        return fail(OFARN_E_INVALID, "flags=%d: only OPTFLOW_USE_INITIAL_FLOW (4) and OPTFLOW_LK_GET_MIN_EIGENVALS (8) exist", p->flags);
-    return OFARN_OK;
-}
-
-// (re)allocates the LK workspace for `frames` frames of w x h and `levels` pyramid levels above level 0
-int ensure_lk_ws(ofarn_ctx *c, int w, int h, int frames, int levels)
-{
-    auto &K = c->lk;
-    if (K.w == w && K.h == h && K.frames >= frames && K.levels >= levels) return OFARN_OK;
-    for (uint8_t *p : K.pyr) if (p) (void)hipFree(p);
-    for (int16_t *p : K.der) if (p) (void)hipFree(p);
-    K = ofarn_ctx::LkWs();
-    K.lw.assign(levels + 1, 0); K.lh.assign(levels + 1, 0);
-    K.pyr.assign(levels + 1, nullptr); K.der.assign(levels + 1, nullptr);
-    for (int l = 0; l <= levels; l++) {
-        K.lw[l] = l == 0 ? w : (K.lw[l - 1] + 1) / 2;
-        K.lh[l] = l == 0 ? h : (K.lh[l - 1] + 1) / 2;
-        const size_t npx = (size_t)K.lw[l] * K.lh[l] * frames;
-        if (l > 0 && hipMalloc((void **)&K.pyr[l], npx + 64) != hipSuccess) { (void)hipGetLastError(); return fail(OFARN_E_NOMEM, "LK pyramid does not fit"); }
-        if (hipMalloc((void **)&K.der[l], npx * 2 * sizeof(int16_t) + 64) != hipSuccess) { (void)hipGetLastError(); return fail(OFARN_E_NOMEM, "LK derivatives do not fit"); }
-    }
-    K.w = w; K.h = h; K.frames = frames; K.levels = levels;
-    return OFARN_OK;
-}
-
-// One wave of pairs: pyramid + derivatives of its frames, then the tracker level by level (coarse to fine).
-int lk_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int nframes, int npairs, int fstep, int i_off, int j_off,
-            int w, int h, const float *d_pts, int npts, int pts_stride, const ofarn_lk_params &prm, float *d_next,
-            uint8_t *d_status, float *d_err)
-{
-    const int levels = lk_levels(w, h, prm.win_w, prm.win_h, prm.max_level);
-    int rc = ensure_lk_ws(c, w, h, nframes, levels);
-    if (rc) return rc;
-    auto &K = c->lk;
-    for (int l = 0; l <= levels; l++) {
-        const uint8_t *img = l == 0 ? d_frames : K.pyr[l];
-        if (l > 0) launch_pyrdown_u8(s, l == 1 ? d_frames : K.pyr[l - 1], K.lw[l - 1], K.lh[l - 1], K.pyr[l], nframes);
-        launch_scharr(s, img, K.lw[l], K.lh[l], K.der[l], nframes);
-    }
-    int max_count = prm.max_count < 0 ? 0 : prm.max_count > 100 ? 100 : prm.max_count;
-    double eps = prm.epsilon < 0 ? 0 : prm.epsilon > 10 ? 10 : prm.epsilon;
-    for (int l = levels; l >= 0; l--) {
-        LkLevelArgs A{};
-        A.img = l == 0 ? d_frames : K.pyr[l];
-        A.deriv = K.der[l];
-        A.pts = d_pts; A.next_pts = d_next; A.status = d_status; A.err = d_err;
-        A.w = K.lw[l]; A.h = K.lh[l]; A.npts = npts; A.pts_stride = pts_stride;
-        A.fstep = fstep; A.i_off = i_off; A.j_off = j_off;
-        A.win_w = prm.win_w; A.win_h = prm.win_h; A.level = l; A.top_level = levels; A.flags = prm.flags; A.max_count = max_count;
-        A.scale = (float)(1. / (1 << l));
-        A.min_eig = (float)prm.min_eig_threshold;
-        A.eps2 = eps * eps;
-        launch_lk_track(s, A, npairs);
-    }
-    HIP_TRY(hipGetLastError());
-    return OFARN_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
-void ofarn_lk_default_params(ofarn_lk_params *p)
-{
-    if (!p) return;
-    // cv2.calcOpticalFlowPyrLK defaults: winSize (21, 21), maxLevel 3, criteria (COUNT + EPS, 30, 0.01), flags 0, 1e-4
-    p->win_w = 21; p->win_h = 21; p->max_level = 3; p->max_count = 30; p->epsilon = 0.01; p->flags = 0; p->min_eig_threshold = 1e-4;
-}
-
-int ofarn_lk_levels(const ofarn_lk_params *p, int w, int h)
-{
-    int rc = check_lk_params(p);
-    if (rc) return rc;
-    if (w < 1 || h < 1) return fail(OFARN_E_INVALID, "empty frame %dx%d", w, h);
-    return lk_levels(w, h, p->win_w, p->win_h, p->max_level);
-}
-
-int ofarn_lk_calc_batch_device(ofarn_ctx *c, const uint8_t *d_frames, int n_frames, int w, int h, int pairs_mode, int reverse,
-                               const float *d_pts, int npts, int pts_per_pair, const ofarn_lk_params *prm, float *d_next_pts,
-                               uint8_t *d_status, float *d_err, void *hip_stream)
-{
-    int rc = check_size(c, w, h);
-    if (rc) return rc;
-    if ((rc = check_lk_params(prm))) return rc;
-    if (!d_frames || !d_pts || !d_next_pts || !d_status || !d_err) return fail(OFARN_E_INVALID, "NULL argument");
-    if (pairs_mode != OFARN_PAIRS_INDEPENDENT && pairs_mode != OFARN_PAIRS_CONSECUTIVE)
-        return fail(OFARN_E_INVALID, "pairs_mode must be 0 or 1");
-    const int n_pairs = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? n_frames - 1 : n_frames / 2;
-    if (n_pairs < 0 || npts < 0 || (pairs_mode == OFARN_PAIRS_INDEPENDENT && (n_frames & 1)))
-        return fail(OFARN_E_INVALID, "n_frames=%d does not form whole pairs in mode %d", n_frames, pairs_mode);
-    if (n_pairs == 0 || npts == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
-    const size_t fsz = (size_t)w * h;
-    const int fstep = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? 1 : 2;
-    const int wave = c->max_batch < 64 ? c->max_batch : 64;      // LK keeps a small workspace of its own
-    // pair p = frames (a, a+1); cv2.calcOpticalFlowPyrLK(prev, next): track FROM prev TO next.  reverse tracks from the
-    // later frame to the earlier one, as pathfinder_viewer.py:156 does (img2 -> img1).
-    const int i_off = reverse ? 1 : 0, j_off = reverse ? 0 : 1;
-    for (int p0 = 0; p0 < n_pairs; p0 += wave) {
-        const int np = n_pairs - p0 < wave ? n_pairs - p0 : wave;
-        const int nf = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? np + 1 : 2 * np;
-        rc = lk_wave(c, s, d_frames + (size_t)p0 * fstep * fsz, nf, np, fstep, i_off, j_off, w, h,
-                     d_pts + (pts_per_pair ? (size_t)p0 * npts * 2 : 0), npts, pts_per_pair ? npts : 0, *prm,
-                     d_next_pts + (size_t)p0 * npts * 2, d_status + (size_t)p0 * npts, d_err + (size_t)p0 * npts);
-        if (rc) return rc;
-    }
-    return OFARN_OK;
-}
-
-int ofarn_lk_calc(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next, int w, int h, int stride, const float *h_pts,
-                  int npts, const ofarn_lk_params *prm, float *h_next_pts, uint8_t *h_status, float *h_err)
-{
-    int rc = check_size(c, w, h);
-    if (rc) return rc;
-    if ((rc = check_lk_params(prm))) return rc;
-    if (!h_prev || !h_next || !h_pts || !h_next_pts || !h_status || !h_err) return fail(OFARN_E_INVALID, "NULL argument");
-    if (stride < w) return fail(OFARN_E_INVALID, "stride %d < width %d", stride, w);
-    if (npts < 0) return fail(OFARN_E_INVALID, "npts < 0");
-    if (npts == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    const size_t fsz = (size_t)w * h;
-    if ((rc = ensure_staging(c, 2 * fsz, 0, 0))) return rc;
-    DevTmp pts, nxt, st, er;
-    if ((rc = pts.alloc((size_t)npts * 8)) || (rc = nxt.alloc((size_t)npts * 8)) || (rc = st.alloc(npts)) || (rc = er.alloc((size_t)npts * 4)))
-        return rc;
-    HIP_TRY(hipMemcpy2DAsync(c->st_frames, w, h_prev, stride, w, h, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpy2DAsync(c->st_frames + fsz, w, h_next, stride, w, h, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(pts.p, h_pts, (size_t)npts * 8, hipMemcpyHostToDevice, c->stream));
-    if (prm->flags & OFARN_LK_USE_INITIAL_FLOW)
-        HIP_TRY(hipMemcpyAsync(nxt.p, h_next_pts, (size_t)npts * 8, hipMemcpyHostToDevice, c->stream));
-    if ((rc = lk_wave(c, c->stream, c->st_frames, 2, 1, 2, 0, 1, w, h, pts.as<float>(), npts, 0, *prm, nxt.as<float>(),
-                      st.as<uint8_t>(), er.as<float>())))
-        return rc;
-    HIP_TRY(hipMemcpyAsync(h_next_pts, nxt.p, (size_t)npts * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(h_status, st.p, npts, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(h_err, er.p, (size_t)npts * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return OFARN_OK;
-}
-
-int ofarn_vector_filter_device(ofarn_ctx *c, const float *d_vecs, int n, int w, int h, uint8_t *d_mask, uint8_t *d_v,
-                               int32_t *d_iflow, void *hip_stream)
-{
-    int rc = check_size(c, w, h);
-    if (rc) return rc;
-    if (!d_vecs || !d_mask || !d_v) return fail(OFARN_E_INVALID, "vectors, mask and v must not be NULL");
-    if (n < 0) return fail(OFARN_E_INVALID, "n < 0");
-    if (n == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    if ((rc = make_plan(c, w, h))) return rc;
-    if (c->P == 0) return OFARN_OK;
-    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
-    launch_grid_filter(s, nullptr, w, h, n, c->d_pts, c->P, c->prm.filter_variant, d_mask, d_v, d_iflow, d_vecs);
-    HIP_TRY(hipGetLastError());
-    return OFARN_OK;
-}
-
-int ofarn_vector_filter(ofarn_ctx *c, const float *h_vecs, int n, int w, int h, uint8_t *h_mask, uint8_t *h_v, int32_t *h_iflow)
-{
-    int rc = check_size(c, w, h);
-    if (rc) return rc;
-    if (!h_vecs || !h_mask || !h_v) return fail(OFARN_E_INVALID, "vectors, mask and v must not be NULL");
-    if (n < 0) return fail(OFARN_E_INVALID, "n < 0");
-    if (n == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    if ((rc = make_plan(c, w, h))) return rc;
-    if (c->P == 0) return OFARN_OK;
-    const size_t P = (size_t)c->P;
-    DevTmp vec, mk, vv, ifl;
-    if ((rc = vec.alloc(P * n * 8)) || (rc = mk.alloc(P * n)) || (rc = vv.alloc(P * n)) || (rc = ifl.alloc(P * n * 8))) return rc;
-    HIP_TRY(hipMemcpyAsync(vec.p, h_vecs, P * n * 8, hipMemcpyHostToDevice, c->stream));
-    launch_grid_filter(c->stream, nullptr, w, h, n, c->d_pts, c->P, c->prm.filter_variant, mk.as<uint8_t>(), vv.as<uint8_t>(),
-                       h_iflow ? ifl.as<int32_t>() : nullptr, vec.as<float>());
-    HIP_TRY(hipMemcpyAsync(h_mask, mk.p, P * n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(h_v, vv.p, P * n, hipMemcpyDeviceToHost, c->stream));
-    if (h_iflow) HIP_TRY(hipMemcpyAsync(h_iflow, ifl.p, P * n * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return OFARN_OK;
-}
-
-int ofarn_stage_pyrdown(ofarn_ctx *c, const uint8_t *h_img, int w, int h, uint8_t *h_out)
-{
-    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
-    if (!h_img || !h_out || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad argument");
-    HIP_TRY(hipSetDevice(c->device));
-    const size_t npx = (size_t)w * h, nout = (size_t)((w + 1) / 2) * ((h + 1) / 2);
-    DevTmp in, out;
-    int rc;
-    if ((rc = in.alloc(npx)) || (rc = out.alloc(nout))) return rc;
-    HIP_TRY(hipMemcpyAsync(in.p, h_img, npx, hipMemcpyHostToDevice, c->stream));
-    launch_pyrdown_u8(c->stream, in.as<uint8_t>(), w, h, out.as<uint8_t>(), 1);
-    HIP_TRY(hipMemcpyAsync(h_out, out.p, nout, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return OFARN_OK;
-}
-
-int ofarn_stage_scharr(ofarn_ctx *c, const uint8_t *h_img, int w, int h, int16_t *h_out)
-{
-    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
-    if (!h_img || !h_out || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad argument");
-    HIP_TRY(hipSetDevice(c->device));
-    const size_t npx = (size_t)w * h;
-    DevTmp in, out;
-    int rc;
-    if ((rc = in.alloc(npx)) || (rc = out.alloc(npx * 4))) return rc;
-    HIP_TRY(hipMemcpyAsync(in.p, h_img, npx, hipMemcpyHostToDevice, c->stream));
-    launch_scharr(c->stream, in.as<uint8_t>(), w, h, out.as<int16_t>(), 1);
-    HIP_TRY(hipMemcpyAsync(h_out, out.p, npx * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return OFARN_OK;
-}
-
-// ------------------------------------------------------------------ single-stage entry points
-// Each uses the context workspace for one image; inputs/outputs are host arrays.
-
-int ofarn_stage_level_image(ofarn_ctx *c, const uint8_t *h_img, int w, int h, int k, float *h_out)
-{
-    int rc = check_size(c, w, h);
-    if (rc) return rc;
-    if (!h_img || !h_out) return fail(OFARN_E_INVALID, "NULL argument");
-    HIP_TRY(hipSetDevice(c->device));
-    if ((rc = make_plan(c, w, h))) return rc;
-    if (k < 0 || k >= (int)c->lv.size()) return fail(OFARN_E_INVALID, "level %d out of range", k);
-    const Level &L = c->lv[k];
-    const size_t fsz = (size_t)w * h;
-    if ((rc = ensure_staging(c, fsz, 0, 0))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->st_frames, h_img, fsz, hipMemcpyHostToDevice, c->stream));
-    const bool lds_ok = (size_t)(w + 2 * (L.ksize / 2)) * 4 * 33 / 32 + 4 * (size_t)L.ksize + 64 <= 60 * 1024;
-    if (!c->force_generic && level_direct_supported(c->st_frames, w, h, L.w, L.h, L.ksize))
-        launch_level_direct(c->stream, c->st_frames, fsz, w, h, 1, L.h_kern.data(), L.ksize, c->ws[0].I, L.w, L.h);
-    else {
-        if (!c->force_generic && level_hdirect_supported(c->st_frames, w, L.w, L.ksize))
-            launch_level_hdirect(c->stream, c->st_frames, fsz, w, h, 1, L.h_kern.data(), L.ksize, c->ws[0].tmp, L.w);
-        else if (!c->force_generic && lds_ok)
-            launch_level_hpass_lds(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->ws[0].tmp);
-        else
-            launch_level_hpass(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->ws[0].tmp);
-        launch_level_vpass(c->stream, c->ws[0].tmp, h, L.w, L.h, 1, L.d_kern, L.ksize, L.d_xa, L.d_yofs, L.d_ya, c->ws[0].I);
-    }
-    HIP_TRY(hipMemcpyAsync(h_out, c->ws[0].I, (size_t)L.w * L.h * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return OFARN_OK;
-}
-
-// host <-> device layout helpers of the single-stage entry points (test-only paths)
-static void r_to_device_layout(const float *h_il, size_t npx, std::vector<float> &dev)   // [npx][5] -> 4+1
-{
-    dev.assign(r_frame_stride(npx), 0.f);
-    for (size_t o = 0; o < npx; o++) {
-        for (int ch = 0; ch < 4; ch++) dev[o * 4 + ch] = h_il[o * 5 + ch];
-        dev[4 * npx + o] = h_il[o * 5 + 4];
-    }
-}
-static void r_from_device_layout(const std::vector<float> &dev, size_t npx, float *h_il)
-{
-    for (size_t o = 0; o < npx; o++) {
-        for (int ch = 0; ch < 4; ch++) h_il[o * 5 + ch] = dev[o * 4 + ch];
-        h_il[o * 5 + 4] = dev[4 * npx + o];
-    }
-}
-
-int ofarn_stage_polyexp(ofarn_ctx *c, const float *h_img, int w, int h, float *h_R)
-{
-    int rc = check_size(c, w, h);
-    if (rc) return rc;
-    if (!h_img || !h_R) return fail(OFARN_E_INVALID, "NULL argument");
-    HIP_TRY(hipSetDevice(c->device));
-    const size_t npx = (size_t)w * h;
-    HIP_TRY(hipMemcpyAsync(c->ws[0].I, h_img, npx * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    if (!c->force_generic && polyexp_march_supported(c->prm.poly_n)) {
-        const float none[3] = {0, 0, 0};
-        launch_polyexp_march(c->stream, c->ws[0].I, npx, 0, c->ws[0].R, w, h, 1, c->poly, none);
-    } else
-        launch_polyexp(c->stream, c->ws[0].I, c->ws[0].R, w, h, 1, c->poly);
-    std::vector<float> dev(r_frame_stride(npx));
-    HIP_TRY(hipMemcpyAsync(dev.data(), c->ws[0].R, dev.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    r_from_device_layout(dev, npx, h_R);
-    return OFARN_OK;
-}
-
-int ofarn_stage_update_matrices(ofarn_ctx *c, const float *h_R0, const float *h_R1, const float *h_flow, int w, int h,
-                                float *h_M)
-{
-    int rc = check_size(c, w, h);
-    if (rc) return rc;
-    if (!h_R0 || !h_R1 || !h_flow || !h_M) return fail(OFARN_E_INVALID, "NULL argument");
-    HIP_TRY(hipSetDevice(c->device));
-    const size_t npx = (size_t)w * h;
-    std::vector<float> d0, d1;
-    r_to_device_layout(h_R0, npx, d0);
-    r_to_device_layout(h_R1, npx, d1);
-    HIP_TRY(hipMemcpyAsync(c->ws[0].R, d0.data(), d0.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->ws[0].R + r_frame_stride(npx), d1.data(), d1.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->ws[0].flowA, h_flow, npx * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    launch_update_matrices(c->stream, c->ws[0].R, 1, c->ws[0].flowA, c->ws[0].M, w, h, 1);
-    std::vector<float> mp(npx * 5);
-    HIP_TRY(hipMemcpyAsync(mp.data(), c->ws[0].M, npx * 5 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    for (size_t o = 0; o < npx; o++)
-        for (int ch = 0; ch < 5; ch++) h_M[o * 5 + ch] = mp[ch * npx + o];     // planar -> interleaved
-    return OFARN_OK;
-}
-
-int ofarn_stage_blur_solve(ofarn_ctx *c, const float *h_M, int w, int h, float *h_flow)
-{
-    int rc = check_size(c, w, h);
-    if (rc) return rc;
-    if (!h_M || !h_flow) return fail(OFARN_E_INVALID, "NULL argument");
-    HIP_TRY(hipSetDevice(c->device));
-    const size_t npx = (size_t)w * h;
-    std::vector<float> mp(npx * 5);
-    for (size_t o = 0; o < npx; o++)
-        for (int ch = 0; ch < 5; ch++) mp[ch * npx + o] = h_M[o * 5 + ch];     // interleaved -> planar
-    HIP_TRY(hipMemcpyAsync(c->ws[0].M, mp.data(), npx * 5 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    if (c->prm.flags & OFARN_FLAG_FARNEBACK_GAUSSIAN)
-        launch_gauss_solve(c->stream, c->ws[0].M, c->ws[0].flowA, w, h, 1, c->prm.winsize, c->d_gwin);
-    else
-        launch_blur_solve(c->stream, c->ws[0].M, c->ws[0].flowA, w, h, 1, c->prm.winsize);
-    HIP_TRY(hipMemcpyAsync(h_flow, c->ws[0].flowA, npx * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return OFARN_OK;
-}
-
-int ofarn_stage_flow_upsample(ofarn_ctx *c, const float *h_flow, int sw, int sh, int dw, int dh, float *h_out)
-{
-    int rc = check_size(c, dw, dh);
-    if (rc) return rc;
-    if ((rc = check_size(c, sw, sh))) return rc;
-    if (!h_flow || !h_out) return fail(OFARN_E_INVALID, "NULL argument");
-    HIP_TRY(hipSetDevice(c->device));
-    std::vector<int> xo, yo;
-    std::vector<float> xa, ya;
-    resize_tables(sw, dw, xo, xa);
-    resize_tables(sh, dh, yo, ya);
-    DevTmp t_xo, t_xa, t_yo, t_ya;
-    if ((rc = t_xo.alloc(dw * sizeof(int))) || (rc = t_xa.alloc(dw * sizeof(float))) || (rc = t_yo.alloc(dh * sizeof(int))) ||
-        (rc = t_ya.alloc(dh * sizeof(float))))
-        return rc;
-    int *d_xo = t_xo.as<int>(), *d_yo = t_yo.as<int>();
-    float *d_xa = t_xa.as<float>(), *d_ya = t_ya.as<float>();
-    HIP_TRY(hipMemcpy(d_xo, xo.data(), dw * sizeof(int), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_xa, xa.data(), dw * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_yo, yo.data(), dh * sizeof(int), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_ya, ya.data(), dh * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpyAsync(c->ws[0].flowA, h_flow, (size_t)sw * sh * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    launch_flow_upsample(c->stream, c->ws[0].flowA, sw, sh, c->ws[0].flowB, dw, dh, 1, d_xo, d_xa, d_yo, d_ya,
-                         (float)(1. / c->prm.pyr_scale));
-    HIP_TRY(hipMemcpyAsync(h_out, c->ws[0].flowB, (size_t)dw * dh * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return OFARN_OK;
-}
-
+#pragma GCC visibility pop
 }  // extern "C"

@@ -1,0 +1,137 @@
+// ofarn_host.h -- host-side internals shared by the C-ABI translation units (ofarn_api*.hip): the context,
+// the error helper, per-call device scratch, per-kernel timing and the plan / workspace helpers of ofarn_api.hip.
+#pragma once
+#include "../../include/ofarn.h"
+#include "ofarn_internal.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace ofarn_host {
+
+// cv2.cvtColor(COLOR_BGR2GRAY) coefficients: color_rgb.simd.hpp RGB2Gray<uchar>, 15-bit fixed point (B, G, R)
+constexpr int kGrayB = 3735, kGrayG = 19235, kGrayR = 9798, kGrayShift = 15;
+
+// thread-local message of the last failing call (ofarn_last_error); returns `code`
+int fail(int code, const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(OFARN_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+// device scratch that lives for one host-pointer call
+struct DevTmp {
+    void *p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+            return fail(OFARN_E_NOMEM, "device scratch of %zu bytes does not fit", bytes);
+        }
+        return OFARN_OK;
+    }
+    template <typename T> T *as() { return static_cast<T *>(p); }
+};
+
+struct Level {
+    int w = 0, h = 0, ksize = 0;
+    double sigma = 0;
+    // device tables
+    float *d_kern = nullptr;
+    float h_kern3[3] = {0, 0, 0};   // host copy of the taps when ksize == 3
+    std::vector<float> h_kern;      // host copy of all taps (passed by value to k_level_direct)
+    int *d_xofs = nullptr, *d_yofs = nullptr;        // image resize W->w, H->h
+    float *d_xa = nullptr, *d_ya = nullptr;
+    int *d_fxofs = nullptr, *d_fyofs = nullptr;      // flow resize (k+1) -> k
+    float *d_fxa = nullptr, *d_fya = nullptr;
+};
+
+}  // namespace ofarn_host
+
+struct ofarn_ctx {
+    ofarn_params prm{};
+    int device = 0;
+    int max_w = 0, max_h = 0, max_batch = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    ofarn::PolyCoef poly{};
+    float *d_gwin = nullptr;     // m+1 taps of the OPTFLOW_FARNEBACK_GAUSSIAN window
+    // plan (cached for one frame size)
+    int plan_w = 0, plan_h = 0;
+    std::vector<ofarn_host::Level> lv;
+    int *d_pts = nullptr;
+    int P = 0;
+    ofarn::AreaTabHost area;            // resize(INTER_AREA) full size -> coarsest level (OPTFLOW_USE_INITIAL_FLOW)
+    float init_scale = 1.f;      // pyr_scale ^ levels, as optflowgf.cpp accumulates it
+    std::vector<void *> plan_allocs;
+    // workspace
+    // two workspaces: waves of one batch alternate between them on two internal streams, so the tail
+    // of one wave's kernels overlaps the other wave's (the second is allocated on first use)
+    struct Workspace { float *tmp = nullptr, *I = nullptr, *R = nullptr, *M = nullptr, *flowA = nullptr, *flowB = nullptr; };
+    Workspace ws[2];
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    bool dual = true;            // OFARN_SINGLE_STREAM=1 disables the second workspace
+    uint64_t ws_bytes = 0;
+    size_t tmp_floats = 0;   // capacity of tmp in floats
+    uint8_t *gray[2] = {nullptr, nullptr};   // gray frames of a wave when the caller hands over BGR (lazy)
+    // sparse LK (lazy): pyramid levels >= 1 (uint8) and Scharr derivatives of every level (int16 x 2) for one wave of frames
+    struct LkWs {
+        int w = 0, h = 0, frames = 0, levels = -1;
+        std::vector<int> lw, lh;
+        std::vector<uint8_t *> pyr;      // pyr[0] unused (level 0 is the caller's frames)
+        std::vector<int16_t *> der;
+    } lk;
+    // host-API staging (lazy)
+    uint8_t *st_frames = nullptr;
+    float *st_flow = nullptr;
+    uint8_t *st_mask = nullptr, *st_v = nullptr;
+    size_t st_frames_cap = 0, st_flow_cap = 0, st_dm_cap = 0;
+    double last_ms = 0;
+    // per-kernel profiling (ofarn_profile_*): hipEvent pairs around each launch, on the launch stream
+    struct ProfRec { int stage, level; double units; hipEvent_t a, b; };
+    bool prof_on = false;
+    bool force_generic = false;   // OFARN_FORCE_GENERIC=1 or ofarn_set_option: use the unfused kernels only
+    int direct_min_frames = 32;   // k_level_direct marches long strips per thread: below this many frames in a wave the
+                                  // row-pass + column-pass pair has more parallelism and lower latency (OFARN_DIRECT_MIN_FRAMES)
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> prof_free;
+    struct ProfAcc { int launches = 0; double ms = 0, units = 0; };
+    ProfAcc prof_acc[OFARN_STAGE_COUNT][32];
+};
+
+namespace ofarn_host {
+
+// ofarn_api.hip
+int check_size(ofarn_ctx *c, int w, int h);
+int make_plan(ofarn_ctx *c, int w, int h);
+int ensure_staging(ofarn_ctx *c, size_t frames_bytes, size_t flow_bytes, size_t dm_bytes);
+int build_area_tab(ofarn_ctx *c, int sw, int sh, int dw, int dh, ofarn::AreaTabHost &out);
+void resize_tables(int ssize, int dsize, std::vector<int> &ofs, std::vector<float> &alpha);
+hipEvent_t prof_event(ofarn_ctx *c);
+
+// Runs `launch` and, when profiling is on, brackets it with two events on the same stream.
+template <typename F>
+inline void timed(ofarn_ctx *c, hipStream_t s, int stage, int level, double units, F &&launch)
+{
+    if (!c->prof_on) { launch(); return; }
+    ofarn_ctx::ProfRec r{stage, level, units, prof_event(c), prof_event(c)};
+    (void)hipEventRecord(r.a, s);
+    launch();
+    (void)hipEventRecord(r.b, s);
+    c->prof_pending.push_back(r);
+}
+
+}  // namespace ofarn_host
