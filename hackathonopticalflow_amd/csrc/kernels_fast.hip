@@ -882,12 +882,12 @@ void launch_level_direct(hipStream_t s, const uint8_t *frames, size_t frame_stri
     else if (W == 8 * w && ksize == 19) launch_level_direct_sk<8, 19>(s, frames, frame_stride, W, H, nframes, h_kern, I, w, h);
 }
 
-// The fused kernel is instantiated for these window half-widths m = winsize/2 (winsize 7..21 and
-// the even sizes sharing an m); other window sizes take the generic unfused kernels.
+// The fused kernel is instantiated for the window half-widths m = winsize/2 = 3..10 (winsize 6..21); other window
+// sizes take the generic unfused kernels.
 bool flow_iter_supported(int winsize)
 {
     const int m = winsize / 2;
-    return m == 3 || m == 5 || m == 7 || m == 10;
+    return m >= 3 && m <= 10;
 }
 
 template <int M_>
@@ -942,7 +942,8 @@ void launch_flow_iter(hipStream_t s, const float *R, int fstep, const float *flo
                               d_xa, d_yofs, d_ya, mul);                                                            \
         break;
     switch (winsize / 2) {
-        OFARN_FI_CASE(3) OFARN_FI_CASE(5) OFARN_FI_CASE(7) OFARN_FI_CASE(10)
+        OFARN_FI_CASE(3) OFARN_FI_CASE(4) OFARN_FI_CASE(5) OFARN_FI_CASE(6) OFARN_FI_CASE(7) OFARN_FI_CASE(8) OFARN_FI_CASE(9)
+        OFARN_FI_CASE(10)
         default: break;
     }
 #undef OFARN_FI_CASE

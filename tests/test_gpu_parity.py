@@ -106,6 +106,11 @@ CASES = [
     (521, 333, 17, dict(levels=2, winsize=11, iterations=2)),
     (300, 260, 18, dict(levels=1, winsize=21)),
     (300, 260, 19, dict(levels=1, winsize=20)),
+    (310, 270, 20, dict(levels=1, winsize=9)),             # m = 4, 6, 8, 9: the remaining fused instantiations
+    (290, 250, 21, dict(levels=2, winsize=13, iterations=2)),
+    (330, 240, 22, dict(levels=1, winsize=17)),
+    (300, 300, 23, dict(levels=1, winsize=19, iterations=2)),
+    (300, 260, 24, dict(levels=1, winsize=23)),            # m = 11: generic kernels
 ]
 
 
