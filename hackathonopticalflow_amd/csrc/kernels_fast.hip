@@ -977,13 +977,12 @@ int best_strip_units(int nunits, int unit, int warm, int blocks_per_strip_row, i
     return best;
 }
 
-bool polyexp_march_supported(int poly_n) { return poly_n == 5; }
+bool polyexp_march_supported(int poly_n) { return poly_n == 5 || poly_n == 7; }   // the two radii OpenCV's documentation names
 
-// src_is_u8 = 1: level 0, src = uint8 frames (stride in bytes = elements); else float level images.
-void launch_polyexp_march(hipStream_t s, const void *src, size_t src_stride, int src_is_u8, float *R, int w, int h,
-                          int nframes, const PolyCoef &c, const float *blur3)
+template <int N>
+static void launch_polyexp_march_n(hipStream_t s, const void *src, size_t src_stride, int src_is_u8, float *R, int w, int h,
+                                   int nframes, const PolyCoef &c, const float *blur3)
 {
-    constexpr int N = 5;
     constexpr int OUTW = FI_THREADS - 2 * N;
     const int strip_h = best_strip_units(h, 1, 2 * N, (int)cdivu(w, OUTW) * nframes, 6);
     dim3 grid(cdivu(w, OUTW), cdivu(h, strip_h), nframes);
@@ -993,6 +992,14 @@ void launch_polyexp_march(hipStream_t s, const void *src, size_t src_stride, int
     else
         hipLaunchKernelGGL((k_polyexp_march<N, 0>), grid, dim3(FI_THREADS), 0, s, src, src_stride, R, w, h, strip_h, c,
                            0.f, 0.f, 0.f);
+}
+
+// src_is_u8 = 1: level 0, src = uint8 frames (stride in bytes = elements); else float level images.
+void launch_polyexp_march(hipStream_t s, const void *src, size_t src_stride, int src_is_u8, float *R, int w, int h,
+                          int nframes, const PolyCoef &c, const float *blur3)
+{
+    if (c.n == 7) launch_polyexp_march_n<7>(s, src, src_stride, src_is_u8, R, w, h, nframes, c, blur3);
+    else launch_polyexp_march_n<5>(s, src, src_stride, src_is_u8, R, w, h, nframes, c, blur3);
 }
 
 void launch_level_hpass_lds(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,

@@ -111,6 +111,8 @@ CASES = [
     (330, 240, 22, dict(levels=1, winsize=17)),
     (300, 300, 23, dict(levels=1, winsize=19, iterations=2)),
     (300, 260, 24, dict(levels=1, winsize=23)),            # m = 11: generic kernels
+    (640, 480, 25, dict(levels=3, poly_n=7, poly_sigma=1.5)),   # the marching polynomial expansion with radius 7
+    (200, 150, 26, dict(levels=1, poly_n=3, poly_sigma=1.0)),   # radius 3: generic polynomial expansion
 ]
 
 
