@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Offline randomized parity sweep (bigger than the seeded fuzz in tests/): random sizes, parameters and flags through the
+whole dense pipeline on the GPU, compared bit for bit with the CPU oracle in the device summation order.
+
+    python tools/bigfuzz.py [seed] [cases]          (needs an MI355X; imports oracle/ as the checker)
+"""
+import sys, os
+sys.path.insert(0, '.')
+import numpy as np
+import hackathonopticalflow_amd as H
+from hackathonopticalflow_amd.synth import translated_pair
+from oracle import oracle as O
+O.build()
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 123)
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+bad = 0
+for i in range(N):
+    w = int(rng.choice([rng.integers(33, 700), 64 * rng.integers(1, 12), 16 * rng.integers(3, 50)]))
+    h = int(rng.choice([rng.integers(33, 500), 32 * rng.integers(2, 14), 16 * rng.integers(3, 30)]))
+    kw = dict(levels=int(rng.integers(0, 6)), winsize=int(rng.integers(3, 27)), iterations=int(rng.integers(1, 4)),
+              poly_n=int(rng.choice([3, 5, 5, 5, 7, 7])), poly_sigma=float(rng.choice([1.1, 1.2, 1.5])),
+              pyr_scale=float(rng.choice([0.5, 0.5, 0.5, 0.6, 0.75, 0.8])), flags=int(rng.choice([0, 0, 0, 4, 256, 260])))
+    os.environ["OFARN_DIRECT_MIN_FRAMES"] = str(int(rng.choice([1, 32])))
+    a, b, (tx, ty) = translated_pair(h, w, 50000 + i, max_shift=5)
+    init = None
+    if kw["flags"] & 4:
+        init = (np.array([tx, ty], np.float32) + rng.standard_normal((h, w, 2)).astype(np.float32)).astype(np.float32)
+    ref = O.farneback(a, b, box_mode=O.BOX_BLOCKED, init_flow=init, **kw)
+    with H.FarnebackEngine(w, h, 1, **kw) as eng:
+        got = eng.calc(a, b, None if init is None else init.copy())
+    if not np.array_equal(got, ref):
+        bad += 1
+        print("MISMATCH", w, h, kw, os.environ["OFARN_DIRECT_MIN_FRAMES"], float(np.abs(got - ref).max()), flush=True)
+print("cases", N, "mismatches", bad)
