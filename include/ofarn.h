@@ -31,7 +31,7 @@ extern "C" {
 
 #define OFARN_OK 0
 #define OFARN_E_INVALID (-1)   /* bad argument (maps to cv2.error / ValueError)                 */
-#define OFARN_E_UNSUPPORTED (-2) /* valid for cv2 but not built yet (flags != 0) */
+#define OFARN_E_UNSUPPORTED (-2) /* outside what is built: unknown flag bits, LK windows wider than 64 */
 #define OFARN_E_HIP (-3)       /* HIP runtime failure                                            */
 #define OFARN_E_NOMEM (-4)     /* workspace does not fit                                         */
 #define OFARN_E_SIZE (-5)      /* frame or batch larger than the context was created for         */
