@@ -43,22 +43,26 @@ void launch_pyrdown_u8(hipStream_t s, const uint8_t *src, int sw, int sh, uint8_
     hipLaunchKernelGGL(k_pyrdown_u8, grid, dim3(256), 0, s, src, sw, sh, dst, dw, dh);
 }
 
-__global__ __launch_bounds__(256) void k_scharr(const uint8_t *__restrict__ src, int w, int h, short2 *__restrict__ dst)
+// frames z0, z0 + zstep, ... (only the frames that serve as the FIRST image of a pair need derivatives)
+__global__ __launch_bounds__(256) void k_scharr(const uint8_t *__restrict__ src, int w, int h, short2 *__restrict__ dst, int z0,
+                                                int zstep)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
-    const uint8_t *s = src + (size_t)blockIdx.z * w * h;
+    const size_t fz = (size_t)z0 + (size_t)blockIdx.z * zstep;
+    const uint8_t *s = src + fz * w * h;
     const uint8_t *r0 = s + (size_t)reflect101(y - 1, h) * w, *r1 = s + (size_t)y * w, *r2 = s + (size_t)reflect101(y + 1, h) * w;
     const int xl = reflect101(x - 1, w), xr = reflect101(x + 1, w);
     const int s_l = (r0[xl] + r2[xl]) * 3 + r1[xl] * 10, s_r = (r0[xr] + r2[xr]) * 3 + r1[xr] * 10;
     const int d_l = r2[xl] - r0[xl], d_c = r2[x] - r0[x], d_r = r2[xr] - r0[xr];
-    dst[(size_t)blockIdx.z * w * h + (size_t)y * w + x] = make_short2((short)(s_r - s_l), (short)((d_r + d_l) * 3 + d_c * 10));
+    dst[fz * w * h + (size_t)y * w + x] = make_short2((short)(s_r - s_l), (short)((d_r + d_l) * 3 + d_c * 10));
 }
 
-void launch_scharr(hipStream_t s, const uint8_t *src, int w, int h, int16_t *dst, int nframes)
+void launch_scharr(hipStream_t s, const uint8_t *src, int w, int h, int16_t *dst, int z0, int zstep, int count)
 {
-    dim3 grid((w + 63) / 64, (h + 3) / 4, nframes);
-    hipLaunchKernelGGL(k_scharr, grid, dim3(256), 0, s, src, w, h, reinterpret_cast<short2 *>(dst));
+    if (count <= 0) return;
+    dim3 grid((w + 63) / 64, (h + 3) / 4, count);
+    hipLaunchKernelGGL(k_scharr, grid, dim3(256), 0, s, src, w, h, reinterpret_cast<short2 *>(dst), z0, zstep);
 }
 
 // ---------------------------------------------------------------------------------------------

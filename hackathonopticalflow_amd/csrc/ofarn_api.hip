@@ -765,7 +765,7 @@ int calc_batch_device_impl(ofarn_ctx *c, const uint8_t *d_frames, bool bgr, int 
     if (use_init && !d_flow) return fail(OFARN_E_INVALID, "OPTFLOW_USE_INITIAL_FLOW needs the flow buffer (it holds the initial flow)");
     HIP_TRY(hipSetDevice(c->device));
     if ((rc = make_plan(c, w, h))) return rc;
-    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    hipStream_t s = pick_stream(c, hip_stream);
     const size_t fsz = (size_t)w * h;
     const int fstep = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? 1 : 2;
     const int nwaves = (n_pairs + c->max_batch - 1) / c->max_batch;
@@ -917,7 +917,7 @@ int ofarn_grid_filter_device(ofarn_ctx *c, const float *d_flow, int n, int w, in
     HIP_TRY(hipSetDevice(c->device));
     if ((rc = make_plan(c, w, h))) return rc;
     if (c->P == 0) return OFARN_OK;
-    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    hipStream_t s = pick_stream(c, hip_stream);
     launch_grid_filter(s, d_flow, w, h, n, c->d_pts, c->P, c->prm.filter_variant, d_mask, d_v, d_iflow);
     HIP_TRY(hipGetLastError());
     return OFARN_OK;

@@ -26,7 +26,7 @@ int ofarn_bgr2gray_device(ofarn_ctx *c, const uint8_t *d_bgr, int n, int w, int 
     if (!d_bgr || !d_gray) return fail(OFARN_E_INVALID, "bgr and gray must not be NULL");
     if (n < 0 || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad size n=%d %dx%d", n, w, h);
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    hipStream_t s = pick_stream(c, hip_stream);
     launch_bgr2gray(s, d_bgr, d_gray, (size_t)n * w * h, kGrayB, kGrayG, kGrayR, kGrayShift);
     HIP_TRY(hipGetLastError());
     return OFARN_OK;
@@ -60,7 +60,7 @@ int ofarn_flow_hsv_device(ofarn_ctx *c, const float *d_flow, int n, int w, int h
     if (!d_flow || (!d_hsv && !d_bgr)) return fail(OFARN_E_INVALID, "flow and at least one of hsv, bgr must not be NULL");
     if (n < 0 || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad size n=%d %dx%d", n, w, h);
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    hipStream_t s = pick_stream(c, hip_stream);
     launch_flow_hsv(s, d_flow, (size_t)n * w * h, d_hsv, d_bgr);
     HIP_TRY(hipGetLastError());
     return OFARN_OK;
@@ -121,7 +121,7 @@ int ofarn_flow_arrows_device(ofarn_ctx *c, const float *d_flow, int n, int w, in
     HIP_TRY(hipSetDevice(c->device));
     double st;
     const int nx = arrow_axis(w, step, &st), ny = arrow_axis(h, step, &st);
-    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    hipStream_t s = pick_stream(c, hip_stream);
     launch_flow_arrows(s, d_flow, w, h, n, nx, ny, st, (double)step, d_lines);
     HIP_TRY(hipGetLastError());
     return OFARN_OK;
@@ -201,7 +201,7 @@ int ofarn_stage_scharr(ofarn_ctx *c, const uint8_t *h_img, int w, int h, int16_t
     int rc;
     if ((rc = in.alloc(npx)) || (rc = out.alloc(npx * 4))) return rc;
     HIP_TRY(hipMemcpyAsync(in.p, h_img, npx, hipMemcpyHostToDevice, c->stream));
-    launch_scharr(c->stream, in.as<uint8_t>(), w, h, out.as<int16_t>(), 1);
+    launch_scharr(c->stream, in.as<uint8_t>(), w, h, out.as<int16_t>(), 0, 1, 1);
     HIP_TRY(hipMemcpyAsync(h_out, out.p, npx * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return OFARN_OK;

@@ -62,7 +62,7 @@ int lk_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int nframes, i
     for (int l = 0; l <= levels; l++) {
         const uint8_t *img = l == 0 ? d_frames : K.pyr[l];
         if (l > 0) launch_pyrdown_u8(s, l == 1 ? d_frames : K.pyr[l - 1], K.lw[l - 1], K.lh[l - 1], K.pyr[l], nframes);
-        launch_scharr(s, img, K.lw[l], K.lh[l], K.der[l], nframes);
+        launch_scharr(s, img, K.lw[l], K.lh[l], K.der[l], i_off, fstep, npairs);   // derivatives of the first image of each pair only
     }
     int max_count = prm.max_count < 0 ? 0 : prm.max_count > 100 ? 100 : prm.max_count;
     double eps = prm.epsilon < 0 ? 0 : prm.epsilon > 10 ? 10 : prm.epsilon;
@@ -118,7 +118,7 @@ int ofarn_lk_calc_batch_device(ofarn_ctx *c, const uint8_t *d_frames, int n_fram
         return fail(OFARN_E_INVALID, "n_frames=%d does not form whole pairs in mode %d", n_frames, pairs_mode);
     if (n_pairs == 0 || npts == 0) return OFARN_OK;
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    hipStream_t s = pick_stream(c, hip_stream);
     const size_t fsz = (size_t)w * h;
     const int fstep = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? 1 : 2;
     const int wave = c->max_batch < 64 ? c->max_batch : 64;      // LK keeps a small workspace of its own
@@ -178,7 +178,7 @@ int ofarn_vector_filter_device(ofarn_ctx *c, const float *d_vecs, int n, int w, 
     HIP_TRY(hipSetDevice(c->device));
     if ((rc = make_plan(c, w, h))) return rc;
     if (c->P == 0) return OFARN_OK;
-    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    hipStream_t s = pick_stream(c, hip_stream);
     launch_grid_filter(s, nullptr, w, h, n, c->d_pts, c->P, c->prm.filter_variant, d_mask, d_v, d_iflow, d_vecs);
     HIP_TRY(hipGetLastError());
     return OFARN_OK;

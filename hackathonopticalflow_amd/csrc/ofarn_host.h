@@ -114,6 +114,14 @@ struct ofarn_ctx {
 
 namespace ofarn_host {
 
+// hip_stream argument of the C-ABI: NULL = the context's own stream, OFARN_STREAM_NULL = HIP's null (legacy default) stream,
+// whose handle 0 could not be told from NULL otherwise; anything else is a hipStream_t.
+inline hipStream_t pick_stream(const ofarn_ctx *c, void *hip_stream)
+{
+    if (hip_stream == OFARN_STREAM_NULL) return nullptr;
+    return hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+}
+
 // ofarn_api.hip
 int check_size(ofarn_ctx *c, int w, int h);
 int make_plan(ofarn_ctx *c, int w, int h);

@@ -120,7 +120,7 @@ void launch_flow_arrows(hipStream_t s, const float *flow, int w, int h, int npai
 
 // ---- sparse pyramidal Lucas-Kanade (kernels_lk.hip) ----
 void launch_pyrdown_u8(hipStream_t s, const uint8_t *src, int sw, int sh, uint8_t *dst, int nframes);
-void launch_scharr(hipStream_t s, const uint8_t *src, int w, int h, int16_t *dst, int nframes);
+void launch_scharr(hipStream_t s, const uint8_t *src, int w, int h, int16_t *dst, int z0, int zstep, int count);
 struct LkLevelArgs {
     const uint8_t *img;      // this level's images of the wave: uint8 [F][h][w]
     const int16_t *deriv;    // Scharr derivatives: int16 [F][h][w][2]

@@ -233,6 +233,15 @@ def _as_gray(a, name):
     return a
 
 
+def _stream_arg(stream):
+    """hip_stream argument of the C-ABI.  None -> NULL = the engine's own (non-blocking) stream.  An integer is a raw
+    hipStream_t handle as torch reports it (torch.cuda.current_stream().cuda_stream); torch's DEFAULT stream has handle 0,
+    which the C-ABI could not tell from NULL, so it is passed as OFARN_STREAM_NULL ((void *)-1, include/ofarn.h)."""
+    if stream is None:
+        return None
+    return C.c_void_p(int(stream) if int(stream) != 0 else -1)
+
+
 def _ptr(t):
     """Device pointer of a torch tensor / anything with data_ptr(), or a raw int."""
     if t is None:
@@ -350,26 +359,26 @@ class FarnebackEngine:
     def calc_batch_device(self, d_frames, n_frames, width, height, pairs_mode=PAIRS_INDEPENDENT,
                           d_flow=None, d_mask=None, d_v=None, stream=None, bgr=False):
         """Device-resident batch: arguments are torch CUDA tensors (or raw device addresses).
-        Enqueues on `stream` (raw hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream;
-        None = the engine's own stream, which is NOT ordered with torch's: tensors produced by pending torch
-        kernels must be synchronised first) and does not synchronise.  bgr=True: d_frames are decoded video
+        Enqueues on `stream` (raw hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream -- 0, torch's
+        default stream, is understood as such; None = the engine's own stream, which is NOT ordered with torch's:
+        tensors produced by pending torch kernels must be synchronised first) and does not synchronise.  bgr=True: d_frames are decoded video
         frames uint8[n_frames,H,W,3] and cv2.cvtColor(COLOR_BGR2GRAY) (DenseOF.py:510) runs on the device
         in front of the flow.  With OPTFLOW_USE_INITIAL_FLOW d_flow holds the initial flows on entry."""
         fn = self._lib.ofarn_calc_batch_device_bgr if bgr else self._lib.ofarn_calc_batch_device
         _check(fn(self._h, _ptr(d_frames), n_frames, width, height, pairs_mode, _ptr(d_flow), _ptr(d_mask), _ptr(d_v),
-                  C.c_void_p(stream) if stream else None))
+                  _stream_arg(stream)))
 
     def bgr2gray_device(self, d_bgr, n, width, height, d_gray, stream=None):
         _check(self._lib.ofarn_bgr2gray_device(self._h, _ptr(d_bgr), n, width, height, _ptr(d_gray),
-                                               C.c_void_p(stream) if stream else None))
+                                               _stream_arg(stream)))
 
     def flow_hsv_device(self, d_flow, n, width, height, d_hsv=None, d_bgr=None, stream=None):
         _check(self._lib.ofarn_flow_hsv_device(self._h, _ptr(d_flow), n, width, height, _ptr(d_hsv), _ptr(d_bgr),
-                                               C.c_void_p(stream) if stream else None))
+                                               _stream_arg(stream)))
 
     def flow_arrows_device(self, d_flow, n, width, height, step, d_lines, stream=None):
         _check(self._lib.ofarn_flow_arrows_device(self._h, _ptr(d_flow), n, width, height, step, _ptr(d_lines),
-                                                  C.c_void_p(stream) if stream else None))
+                                                  _stream_arg(stream)))
 
     # ------------------------------------------------------------------ sparse pyramidal Lucas-Kanade
     def lk(self, prev, next, pts, next_pts=None, **lk_kw):
@@ -404,7 +413,7 @@ class FarnebackEngine:
         _check(self._lib.ofarn_lk_calc_batch_device(self._h, _ptr(d_frames), n_frames, width, height, pairs_mode,
                                                     int(bool(reverse)), _ptr(d_pts), npts, int(bool(pts_per_pair)),
                                                     C.byref(p), _ptr(d_next_pts), _ptr(d_status), _ptr(d_err),
-                                                    C.c_void_p(stream) if stream else None))
+                                                    _stream_arg(stream)))
 
     def vector_filter(self, vecs, width, height, return_flow=False):
         """pathfinder_viewer.py:159-176 + 204-217 on vectors given AT the grid points (float32[P,2] or [n,P,2]),
@@ -427,7 +436,7 @@ class FarnebackEngine:
 
     def vector_filter_device(self, d_vecs, n, width, height, d_mask, d_v, d_iflow=None, stream=None):
         _check(self._lib.ofarn_vector_filter_device(self._h, _ptr(d_vecs), n, width, height, _ptr(d_mask), _ptr(d_v),
-                                                    _ptr(d_iflow), C.c_void_p(stream) if stream else None))
+                                                    _ptr(d_iflow), _stream_arg(stream)))
 
     def stage_pyrdown(self, img):
         img = np.ascontiguousarray(_as_gray(img, "img"))
@@ -499,7 +508,7 @@ class FarnebackEngine:
 
     def danger_map_device(self, d_flow, n, width, height, d_mask, d_v, d_iflow=None, stream=None):
         _check(self._lib.ofarn_grid_filter_device(self._h, _ptr(d_flow), n, width, height, _ptr(d_mask),
-                                                  _ptr(d_v), _ptr(d_iflow), C.c_void_p(stream) if stream else None))
+                                                  _ptr(d_v), _ptr(d_iflow), _stream_arg(stream)))
 
     # ------------------------------------------------------------------ per-kernel timing
     STAGES = ("level_hpass", "level_vpass", "polyexp", "flow_upsample", "update_matrices", "blur_solve",

@@ -90,7 +90,10 @@ int ofarn_calc_batch(ofarn_ctx *ctx, const uint8_t *h_frames, int n_frames, int 
                      int pairs_mode, float *h_flow, uint8_t *h_mask, uint8_t *h_v);
 
 /* Same, device-resident: all pointers are HBM addresses on the context's GPU; work is enqueued on
- * `hip_stream` (a hipStream_t, NULL = the context's own stream) and NOT synchronised. */
+ * `hip_stream` and NOT synchronised.  `hip_stream` is a hipStream_t; NULL = the context's own non-blocking
+ * stream; HIP's null (legacy default) stream, whose handle is also 0, is named by OFARN_STREAM_NULL.  The
+ * same holds for every `hip_stream` argument below. */
+#define OFARN_STREAM_NULL ((void *)(intptr_t)-1)
 int ofarn_calc_batch_device(ofarn_ctx *ctx, const uint8_t *d_frames, int n_frames, int w, int h,
                             int pairs_mode, float *d_flow, uint8_t *d_mask, uint8_t *d_v,
                             void *hip_stream);
