@@ -755,3 +755,24 @@ def test_fuzz_lk_bit_exact(H, oracle, w, h, seed, kw):
     np.testing.assert_array_equal(got_s[:, 0], ref_s)
     np.testing.assert_array_equal(got_n, ref_n)
     np.testing.assert_array_equal(got_e[:, 0], ref_e)
+
+
+def test_torch_default_stream_is_respected(H, oracle):
+    """torch's default stream has handle 0; the Python mirror must enqueue on THAT stream (not on the engine's own), so work
+    torch has queued but not finished -- here the copy that fills the frames behind a long matmul -- is seen by the kernels."""
+    torch = pytest.importorskip("torch")
+    h, w = 120, 160
+    a, b, _ = translated_pair(h, w, 91, max_shift=3)
+    src = torch.from_numpy(np.stack([a, b])).cuda()
+    d_frames = torch.zeros_like(src)
+    d_flow = torch.zeros((1, h, w, 2), dtype=torch.float32, device="cuda")
+    big = torch.randn((6144, 6144), device="cuda")
+    with H.FarnebackEngine(w, h, 1, levels=2) as eng:
+        torch.cuda.synchronize()
+        for _ in range(6):
+            big = big @ big * 1e-3                      # keeps the default stream busy for a while
+        d_frames.copy_(src)                             # queued behind the matmuls
+        eng.calc_batch_device(d_frames, 2, w, h, H.PAIRS_INDEPENDENT, d_flow, None, None,
+                              stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    np.testing.assert_array_equal(d_flow[0].cpu().numpy(), oracle.farneback(a, b, levels=2, box_mode=oracle.BOX_BLOCKED))
