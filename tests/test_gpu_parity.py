@@ -768,6 +768,9 @@ def test_torch_default_stream_is_respected(H, oracle):
     d_flow = torch.zeros((1, h, w, 2), dtype=torch.float32, device="cuda")
     big = torch.randn((6144, 6144), device="cuda")
     with H.FarnebackEngine(w, h, 1, levels=2) as eng:
+        eng.calc_batch_device(src, 2, w, h, H.PAIRS_INDEPENDENT, d_flow, None, None)   # warm-up: builds the plan (which synchronises)
+        torch.cuda.synchronize()
+        d_flow.zero_()
         torch.cuda.synchronize()
         for _ in range(6):
             big = big @ big * 1e-3                      # keeps the default stream busy for a while
