@@ -30,8 +30,8 @@ for r in csv.DictReader(open(prof_dir + "/runc_kernel_trace.csv")):
 with open("profiles/r01_kernel_stats_by_grid.csv", "w") as o:
     o.write("# Derived from the kernel trace of the same rocprofv3 --kernel-trace --stats run as r01_kernel_stats.csv.\n"
             "# Split per kernel, grid (= pyramid level) and stream.  bench.py measures roofline.kernel_avg_ms with HIP events over its timed\n"
-            "# region, in which per-kernel profiling keeps all waves on ONE stream (kernels do not overlap): compare with the rows of the\n"
-            "# stream 1 (the caller's).  The warm-up step runs with per-kernel timing off on two internal streams (ids 2 and 3), where\n"
+            "# region, in which per-kernel profiling keeps all waves on ONE stream (kernels do not overlap): compare with the rows of\n"
+            "# stream 0 (the caller's: torch's default stream).  The warm-up step runs with per-kernel timing off on two internal streams (ids 2 and 3), where\n"
             "# kernels of two waves overlap and each one's duration is about doubled.\n")
     o.write("kernel,grid_x,grid_y,grid_z,stream_id,calls,avg_ns,total_ns\n")
     for k in sorted(acc, key=lambda k: -sum(acc[k])):
