@@ -242,8 +242,20 @@ def _stream_arg(stream):
     return C.c_void_p(int(stream) if int(stream) != 0 else -1)
 
 
-def _ptr(t):
-    """Device pointer of a torch tensor / anything with data_ptr(), or a raw int."""
+def _ptr(t, name=None, dtype=None, min_elems=0):
+    """Device pointer of a torch tensor / anything with data_ptr(), or a raw int.  For tensors, `dtype` ("uint8", "float32",
+    "int32") and `min_elems` are checked, together with contiguity and device residency: a wrong tensor would otherwise be
+    read or overwritten silently by the kernels."""
+    if t is not None and not isinstance(t, int) and hasattr(t, "is_contiguous"):
+        nm = name or "tensor"
+        if not t.is_contiguous():
+            raise ValueError(f"{nm} must be contiguous")
+        if hasattr(t, "is_cuda") and not t.is_cuda:
+            raise ValueError(f"{nm} must live on the GPU")
+        if dtype is not None and str(t.dtype) != "torch." + dtype:
+            raise ValueError(f"{nm} must be {dtype}, got {t.dtype}")
+        if min_elems and t.numel() < min_elems:
+            raise ValueError(f"{nm} holds {t.numel()} elements, needs at least {min_elems}")
     if t is None:
         return None
     if isinstance(t, int):
@@ -365,19 +377,28 @@ class FarnebackEngine:
         frames uint8[n_frames,H,W,3] and cv2.cvtColor(COLOR_BGR2GRAY) (DenseOF.py:510) runs on the device
         in front of the flow.  With OPTFLOW_USE_INITIAL_FLOW d_flow holds the initial flows on entry."""
         fn = self._lib.ofarn_calc_batch_device_bgr if bgr else self._lib.ofarn_calc_batch_device
-        _check(fn(self._h, _ptr(d_frames), n_frames, width, height, pairs_mode, _ptr(d_flow), _ptr(d_mask), _ptr(d_v),
-                  _stream_arg(stream)))
+        npx = width * height
+        n_pairs = max(n_frames - 1 if pairs_mode == PAIRS_CONSECUTIVE else n_frames // 2, 0)
+        P = len(grid_points(width, height, self.params.grid_step)) if (d_mask is not None or d_v is not None) else 0
+        _check(fn(self._h, _ptr(d_frames, "d_frames", "uint8", n_frames * npx * (3 if bgr else 1)), n_frames, width, height,
+                  pairs_mode, _ptr(d_flow, "d_flow", "float32", n_pairs * npx * 2), _ptr(d_mask, "d_mask", "uint8", n_pairs * P),
+                  _ptr(d_v, "d_v", "uint8", n_pairs * P), _stream_arg(stream)))
 
     def bgr2gray_device(self, d_bgr, n, width, height, d_gray, stream=None):
-        _check(self._lib.ofarn_bgr2gray_device(self._h, _ptr(d_bgr), n, width, height, _ptr(d_gray),
+        _check(self._lib.ofarn_bgr2gray_device(self._h, _ptr(d_bgr, "d_bgr", "uint8", n * width * height * 3), n, width, height,
+                                               _ptr(d_gray, "d_gray", "uint8", n * width * height),
                                                _stream_arg(stream)))
 
     def flow_hsv_device(self, d_flow, n, width, height, d_hsv=None, d_bgr=None, stream=None):
-        _check(self._lib.ofarn_flow_hsv_device(self._h, _ptr(d_flow), n, width, height, _ptr(d_hsv), _ptr(d_bgr),
+        npx = n * width * height
+        _check(self._lib.ofarn_flow_hsv_device(self._h, _ptr(d_flow, "d_flow", "float32", npx * 2), n, width, height,
+                                               _ptr(d_hsv, "d_hsv", "uint8", npx * 3), _ptr(d_bgr, "d_bgr", "uint8", npx * 3),
                                                _stream_arg(stream)))
 
     def flow_arrows_device(self, d_flow, n, width, height, step, d_lines, stream=None):
-        _check(self._lib.ofarn_flow_arrows_device(self._h, _ptr(d_flow), n, width, height, step, _ptr(d_lines),
+        K = self._lib.ofarn_flow_arrow_count(width, height, int(step), None, None)
+        _check(self._lib.ofarn_flow_arrows_device(self._h, _ptr(d_flow, "d_flow", "float32", n * width * height * 2), n, width,
+                                                  height, step, _ptr(d_lines, "d_lines", "int32", n * max(K, 0) * 4),
                                                   _stream_arg(stream)))
 
     # ------------------------------------------------------------------ sparse pyramidal Lucas-Kanade
@@ -410,9 +431,14 @@ class FarnebackEngine:
         """Device-resident LK for a stack of frames: pair p tracks the npts points from its first frame to its second
         (reverse=True: from the second to the first, as pathfinder_viewer.py:156)."""
         p = make_lk_params(**lk_kw)
-        _check(self._lib.ofarn_lk_calc_batch_device(self._h, _ptr(d_frames), n_frames, width, height, pairs_mode,
-                                                    int(bool(reverse)), _ptr(d_pts), npts, int(bool(pts_per_pair)),
-                                                    C.byref(p), _ptr(d_next_pts), _ptr(d_status), _ptr(d_err),
+        n_pairs = max(n_frames - 1 if pairs_mode == PAIRS_CONSECUTIVE else n_frames // 2, 0)
+        _check(self._lib.ofarn_lk_calc_batch_device(self._h, _ptr(d_frames, "d_frames", "uint8", n_frames * width * height),
+                                                    n_frames, width, height, pairs_mode, int(bool(reverse)),
+                                                    _ptr(d_pts, "d_pts", "float32", npts * 2 * (n_pairs if pts_per_pair else 1)),
+                                                    npts, int(bool(pts_per_pair)), C.byref(p),
+                                                    _ptr(d_next_pts, "d_next_pts", "float32", n_pairs * npts * 2),
+                                                    _ptr(d_status, "d_status", "uint8", n_pairs * npts),
+                                                    _ptr(d_err, "d_err", "float32", n_pairs * npts),
                                                     _stream_arg(stream)))
 
     def vector_filter(self, vecs, width, height, return_flow=False):
@@ -435,8 +461,10 @@ class FarnebackEngine:
         return (mask[0], val[0]) if single else (mask, val)
 
     def vector_filter_device(self, d_vecs, n, width, height, d_mask, d_v, d_iflow=None, stream=None):
-        _check(self._lib.ofarn_vector_filter_device(self._h, _ptr(d_vecs), n, width, height, _ptr(d_mask), _ptr(d_v),
-                                                    _ptr(d_iflow), _stream_arg(stream)))
+        P = len(grid_points(width, height, self.params.grid_step))
+        _check(self._lib.ofarn_vector_filter_device(self._h, _ptr(d_vecs, "d_vecs", "float32", n * P * 2), n, width, height,
+                                                    _ptr(d_mask, "d_mask", "uint8", n * P), _ptr(d_v, "d_v", "uint8", n * P),
+                                                    _ptr(d_iflow, "d_iflow", "int32", n * P * 2), _stream_arg(stream)))
 
     def stage_pyrdown(self, img):
         img = np.ascontiguousarray(_as_gray(img, "img"))
@@ -507,8 +535,10 @@ class FarnebackEngine:
         return lines[0] if single else lines
 
     def danger_map_device(self, d_flow, n, width, height, d_mask, d_v, d_iflow=None, stream=None):
-        _check(self._lib.ofarn_grid_filter_device(self._h, _ptr(d_flow), n, width, height, _ptr(d_mask),
-                                                  _ptr(d_v), _ptr(d_iflow), _stream_arg(stream)))
+        P = len(grid_points(width, height, self.params.grid_step))
+        _check(self._lib.ofarn_grid_filter_device(self._h, _ptr(d_flow, "d_flow", "float32", n * width * height * 2), n, width,
+                                                  height, _ptr(d_mask, "d_mask", "uint8", n * P), _ptr(d_v, "d_v", "uint8", n * P),
+                                                  _ptr(d_iflow, "d_iflow", "int32", n * P * 2), _stream_arg(stream)))
 
     # ------------------------------------------------------------------ per-kernel timing
     STAGES = ("level_hpass", "level_vpass", "polyexp", "flow_upsample", "update_matrices", "blur_solve",

@@ -357,6 +357,24 @@ def test_device_resident_batch_torch(H, oracle):
         assert torch.equal(d_mask, d_mask2) and torch.equal(d_v, d_v2)
 
 
+def test_device_tensor_validation(H):
+    torch = pytest.importorskip("torch")
+    h, w = 64, 96
+    fr = torch.zeros((2, h, w), dtype=torch.uint8, device="cuda")
+    fl = torch.zeros((1, h, w, 2), dtype=torch.float32, device="cuda")
+    with H.FarnebackEngine(w, h, 1, levels=1) as eng:
+        with pytest.raises(ValueError, match="uint8"):
+            eng.calc_batch_device(fr.float(), 2, w, h, H.PAIRS_INDEPENDENT, fl, None, None)
+        with pytest.raises(ValueError, match="at least"):
+            eng.calc_batch_device(fr, 2, w, h, H.PAIRS_INDEPENDENT, fl[:, : h // 2], None, None)
+        with pytest.raises(ValueError, match="contiguous"):
+            eng.calc_batch_device(fr, 2, w, h, H.PAIRS_INDEPENDENT, fl.permute(0, 2, 1, 3), None, None)
+        with pytest.raises(ValueError, match="GPU"):
+            eng.calc_batch_device(fr.cpu(), 2, w, h, H.PAIRS_INDEPENDENT, fl, None, None)
+        with pytest.raises(ValueError, match="float32"):
+            eng.flow_hsv_device(fl.double(), 1, w, h, None, torch.zeros((1, h, w, 3), dtype=torch.uint8, device="cuda"))
+
+
 # ------------------------------------------------------------------------------------ errors
 def test_argument_errors(H):
     a = np.zeros((64, 64), np.uint8)
