@@ -1,25 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py -- frame-pairs/s of the dense Farneback hot path at 1920x1080 (levels=5, iterations=3).
+"""bench.py -- frame-pairs/s of the dense Farneback hot path (BASELINE.json metric and configs).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--wave V]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,3,4,5}] [--family translated|warped]
 
-A "step" is one pass of the hot path over one batch of B synthetic translated-noise frame pairs
-per GPU (BASELINE config 3: B = 512 at 1920x1080, inputs resident in HBM before the timed region,
-flow written to HBM, danger maps computed; with N > 1 ranks the danger maps are all-gathered over
-RCCL inside the timed region).  Weak scaling: every rank processes its own B pairs.
+With --gpus N > 1 and no torch.distributed environment, bench.py starts its own N ranks: a fresh child
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` is spawned BEFORE this
+process touches the GPU, and its exit code is returned.  Under torch.distributed.run (RANK / WORLD_SIZE set) it is a rank.
+
+A "step" is one pass of the hot path over one batch of synthetic frame pairs, inputs resident in HBM before the timed
+region, flow written to HBM, danger maps computed; with N > 1 the danger maps are all-gathered over RCCL inside the
+timed region.  Configs (BASELINE.json `configs`):
+
+  3 (default)  1920x1080, levels=5, iterations=3, 512 pairs PER GPU           -> "scaling": "weak"
+  4            the same 512 pairs in total, 512/N per GPU, RCCL gather       -> "scaling": "strong"
+  5            3840x2160, levels=6, iterations=5, 64 pairs in total, 64/N per GPU -> "strong"
+  2            one 1920x1080 pair through the host-pointer drop-in call (ofarn_calc): latency in ms
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline      dominant kernel's algorithmic bytes per launch / its mean launch duration, measured
-                live with hipEvent pairs on the launch stream (ofarn_profile_*), against 8 TB/s.
-  cpu_baseline  the CPU oracle (oracle/farneback_oracle.c, kind "port") timed on a bounded sample
-                of the same workload on this box's host cores (rank 0, N = 1 only).
+  roofline      dominant kernel's algorithmic bytes per launch / its mean launch duration, measured live with hipEvent
+                pairs on the launch stream (ofarn_profile_*), against 8 TB/s; `traffic` = HBM bytes per launch from
+                the separate rocprofv3 --pmc passes kept in profiles/pmc_traffic.json (a profiler cannot run inside the
+                bench), `traffic_frac` = traffic / kernel time / 8 TB/s -- the real bandwidth utilisation.
+  cpu_baseline  the CPU oracle (oracle/farneback_oracle.c, kind "port") timed on a bounded sample of the same workload
+                on this box's host cores (rank 0, N = 1 only); `cores` = threads used.
+  parity        on the CPU sample: EPE vs the oracle (OpenCV-order sums), EPE vs ground truth, and the symmetric
+                difference between the danger index sets from GPU flow and from OpenCV-order flow.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,9 +42,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-W, H = 1920, 1080
-PARAMS = dict(pyr_scale=0.5, levels=5, winsize=15, iterations=3, poly_n=5, poly_sigma=1.2, flags=0)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+CONFIGS = {
+    2: dict(w=1920, h=1080, levels=5, iterations=3, global_pairs=1, scaling="weak", key="1080p_L5_I3"),
+    3: dict(w=1920, h=1080, levels=5, iterations=3, per_gpu_pairs=512, scaling="weak", key="1080p_L5_I3"),
+    4: dict(w=1920, h=1080, levels=5, iterations=3, global_pairs=512, scaling="strong", key="1080p_L5_I3"),
+    5: dict(w=3840, h=2160, levels=6, iterations=5, global_pairs=64, scaling="strong", key="4k_L6_I5"),
+}
 
 # Algorithmic bytes per work unit of each stage (declared inputs read once, outputs
 # written once).  Units: level pixels x frames for A/B, level pixels x pairs for C/D/E.
@@ -59,125 +77,313 @@ def algorithmic_bytes_per_pair(w, h, plan, iterations):
     return float(a + b + c + d + e)
 
 
-def make_frames_gpu(torch, n_pairs, seed0, device):
-    """Translated smooth-noise pairs generated on the GPU (SURVEY 8(d) construction: low-passed
-    white noise, sigma 4 px, quantised to uint8, `next` an integer translation of `prev`).
-    Returns frames uint8[2*n_pairs, H, W] (prev0, next0, prev1, ...) and shifts int[n_pairs, 2]."""
-    pad = 16
+def self_launch(args, argv):
+    """--gpus N > 1 outside torch.distributed.run: start the ranks as a fresh child.  Nothing in this process has
+    touched HIP yet (torch is not even imported), and the child is a new process, not an exec of this one."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def smooth_base_gpu(torch, hh, ww, seed, device, sigma=4.0):
+    """Low-passed white noise, float32 [hh, ww] on the GPU."""
     r = 16
     x = torch.arange(-r, r + 1, device=device, dtype=torch.float32)
-    k = torch.exp(-0.5 * (x / 4.0) ** 2)
+    k = torch.exp(-0.5 * (x / sigma) ** 2)
     k = (k / k.sum())
-    frames = torch.empty((2 * n_pairs, H, W), dtype=torch.uint8, device=device)
-    shifts = np.empty((n_pairs, 2), np.int64)
     g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    base = torch.randn((1, 1, hh, ww), generator=g, device=device)
+    base = torch.nn.functional.pad(base, (r, r, 0, 0), mode="circular")
+    base = torch.nn.functional.conv2d(base, k.view(1, 1, 1, -1))
+    base = torch.nn.functional.pad(base, (0, 0, r, r), mode="circular")
+    base = torch.nn.functional.conv2d(base, k.view(1, 1, -1, 1))[0, 0]
+    lo, hi = base.min(), base.max()
+    return (base - lo) * (255.0 / (hi - lo))
+
+
+def make_frames_gpu(torch, n_pairs, seed0, device, W, H, family):
+    """Synthetic pairs generated on the GPU.  Returns frames uint8[2*n_pairs, H, W] (prev0, next0, prev1, ...) and the
+    ground-truth flow: shifts int[n_pairs, 2] for "translated" (`next` an integer translation of `prev`), or
+    a list of float32[H, W, 2] CPU arrays for "warped" (zoom about the frame centre + rotation + sub-pixel shift, the
+    FPV forward-flight field of the reference's use case; bicubic resampling)."""
+    frames = torch.empty((2 * n_pairs, H, W), dtype=torch.uint8, device=device)
+    if family == "translated":
+        pad = 16
+        shifts = np.empty((n_pairs, 2), np.int64)
+        for i in range(n_pairs):
+            img = torch.round(smooth_base_gpu(torch, H + 2 * pad, W + 2 * pad, seed0 + i, device)).to(torch.uint8)
+            rs = np.random.default_rng(seed0 + i)
+            tx, ty = (int(v) for v in rs.integers(-8, 9, size=2))
+            shifts[i] = (tx, ty)
+            frames[2 * i] = img[pad:pad + H, pad:pad + W]
+            frames[2 * i + 1] = img[pad - ty:pad - ty + H, pad - tx:pad - tx + W]
+        return frames, shifts
+    gts = []
+    ys, xs = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float32),
+                            torch.arange(W, device=device, dtype=torch.float32), indexing="ij")
+    cx, cy = float(W // 2), float(H // 2)
     for i in range(n_pairs):
-        g.manual_seed(seed0 + i)
-        base = torch.randn((1, 1, H + 2 * pad, W + 2 * pad), generator=g, device=device)
-        base = torch.nn.functional.pad(base, (r, r, 0, 0), mode="circular")
-        base = torch.nn.functional.conv2d(base, k.view(1, 1, 1, -1))
-        base = torch.nn.functional.pad(base, (0, 0, r, r), mode="circular")
-        base = torch.nn.functional.conv2d(base, k.view(1, 1, -1, 1))[0, 0]
-        lo, hi = base.min(), base.max()
-        img = torch.round((base - lo) * (255.0 / (hi - lo))).to(torch.uint8)
         rs = np.random.default_rng(seed0 + i)
-        tx, ty = (int(v) for v in rs.integers(-8, 9, size=2))
-        shifts[i] = (tx, ty)
-        frames[2 * i] = img[pad:pad + H, pad:pad + W]
-        frames[2 * i + 1] = img[pad - ty:pad - ty + H, pad - tx:pad - tx + W]
-    return frames, shifts
+        zoom, ang = float(rs.uniform(1.005, 1.03)), float(np.deg2rad(rs.uniform(-1.0, 1.0)))
+        tx, ty = float(rs.uniform(-3, 3)), float(rs.uniform(-3, 3))
+        a00, a01, a10, a11 = zoom * np.cos(ang), -zoom * np.sin(ang), zoom * np.sin(ang), zoom * np.cos(ang)
+        fx = a00 * (xs - cx) + a01 * (ys - cy) + tx - (xs - cx)
+        fy = a10 * (xs - cx) + a11 * (ys - cy) + ty - (ys - cy)
+        pad = int(max(float(fx.abs().max()), float(fy.abs().max()))) + 12
+        base = smooth_base_gpu(torch, H + 2 * pad, W + 2 * pad, seed0 + i, device)
+        det = a00 * a11 - a01 * a10
+        qx, qy = xs - cx - tx, ys - cy - ty
+        px = cx + (a11 * qx - a01 * qy) / det + pad
+        py = cy + (-a10 * qx + a00 * qy) / det + pad
+        grid = torch.stack([(px + 0.5) / (W + 2 * pad) * 2 - 1, (py + 0.5) / (H + 2 * pad) * 2 - 1], -1)[None]
+        nxt = torch.nn.functional.grid_sample(base[None, None], grid, mode="bicubic", padding_mode="reflection",
+                                              align_corners=False)[0, 0]
+        frames[2 * i] = torch.round(base[pad:pad + H, pad:pad + W]).clamp(0, 255).to(torch.uint8)
+        frames[2 * i + 1] = torch.round(nxt).clamp(0, 255).to(torch.uint8)
+        gts.append(torch.stack([fx, fy], -1).cpu().numpy())
+    return frames, gts
 
 
-def cpu_baseline(frames_np, gpu_flow_np, n_sample, shifts=None):
-    """Times the CPU oracle on the first n_sample pairs: one thread, then OpenMP across pairs.
-    Also returns the endpoint errors of SURVEY 8(d): GPU vs oracle over all pixels, and both vs the ground truth
-    (the integer translation of the synthetic pair) on the interior, >= 32 px from the border."""
+def cpu_baseline(frames_np, n_sample, params, threads):
+    """Times the CPU oracle on the first n_sample pairs: one pair on one thread, then OpenMP across pairs on `threads`
+    threads.  Returns the cpu_baseline object and the oracle flows (OpenCV-order sums) of the sample."""
     from oracle import oracle as O
     O.build()
     fr = np.ascontiguousarray(frames_np[:2 * n_sample])
     t0 = time.perf_counter()
-    ref1 = O.farneback_batch(fr[:2], 0, nthreads=1, **PARAMS)
+    ref1 = O.farneback_batch(fr[:2], 0, nthreads=1, **params)
     t1 = time.perf_counter() - t0
-    cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), O.omp_max_threads(), n_sample))
+    cores = max(1, min(threads, O.omp_max_threads(), n_sample))
     t0 = time.perf_counter()
-    ref = O.farneback_batch(fr, 0, nthreads=cores, **PARAMS)
+    ref = O.farneback_batch(fr, 0, nthreads=cores, **params)
     tn = time.perf_counter() - t0
-    epe = np.linalg.norm(gpu_flow_np[:n_sample].astype(np.float64) - ref.astype(np.float64), axis=-1)
     assert np.array_equal(ref[0], ref1[0])
-    gt = None
-    if shifts is not None:
-        g = np.asarray(shifts[:n_sample], np.float64)[:, None, None, :]
-        inner = (slice(None), slice(32, -32), slice(32, -32))
-        gt = {"gpu_mean": float(np.linalg.norm(gpu_flow_np[:n_sample][inner] - g, axis=-1).mean()),
-              "cpu_oracle_mean": float(np.linalg.norm(ref[inner] - g, axis=-1).mean())}
     return {
         "value": round(n_sample / tn, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
         "sample": f"first {n_sample} pairs of the workload, oracle/farneback_oracle.c (OpenCV-algorithm CPU "
-                  f"restatement, literal running-sum order), OpenMP across pairs; single thread: "
+                  f"restatement, literal running-sum order), OpenMP across pairs on {cores} threads; single thread: "
                   f"{1 / t1:.4f} pairs/s on 1 pair",
         "single_thread_value": round(1 / t1, 4),
-        "host_cpus": os.cpu_count(),
-    }, {"mean": float(epe.mean()), "p999": float(np.quantile(epe, 0.999)), "max": float(epe.max())}, gt
+        "host_cpus": os.cpu_count(), "host_cpus_usable": len(os.sched_getaffinity(0)),
+    }, ref
+
+
+def parity_report(ofa, gpu_flow, gpu_mask, ref, gt, W, H, family):
+    """EPE of the GPU flow vs the oracle's OpenCV-order flow and vs ground truth, and the symmetric difference of the
+    danger index sets (GPU mask from GPU flow vs the reference's NumPy filter on the OpenCV-order flow)."""
+    from oracle import oracle as O
+    n = len(ref)
+    e = np.linalg.norm(gpu_flow.astype(np.float64) - ref.astype(np.float64), axis=-1)
+    out = {"pairs": n, "family": family,
+           "epe_vs_cpu_oracle": {"mean": float(e.mean()), "p999": float(np.quantile(e, 0.999)), "max": float(e.max())}}
+    inner = (slice(32, -32), slice(32, -32))
+    g_gpu, g_cpu = [], []
+    for i in range(n):
+        g = np.asarray(gt[i], np.float64)
+        g = g[None, None, :] if g.ndim == 1 else g[inner]
+        g_gpu.append(np.linalg.norm(gpu_flow[i][inner] - g, axis=-1).mean())
+        g_cpu.append(np.linalg.norm(ref[i][inner] - g, axis=-1).mean())
+    out["epe_vs_ground_truth_interior_px"] = {"gpu_mean": float(np.mean(g_gpu)), "cpu_oracle_mean": float(np.mean(g_cpu))}
+    sym = same = 0
+    for i in range(n):
+        m_lit, _ = O.danger_map_numpy(ref[i], W, H, 30)
+        m_own, _ = O.danger_map_numpy(gpu_flow[i], W, H, 30)
+        sym += int((gpu_mask[i] != m_lit).sum())
+        same += int((gpu_mask[i] != m_own).sum())
+    out["danger_set_symmetric_difference"] = {
+        "gpu_flow_vs_opencv_order_flow": sym, "gpu_filter_vs_numpy_filter_same_flow": same,
+        "grid_points": int(n * gpu_mask.shape[1]),
+        "note": "index sets from the GPU's flow vs from the CPU oracle's flow in OpenCV's literal summation order "
+                "(flows differ by ~1e-6 px); on the same flow the GPU filter equals the reference's NumPy lines"}
+    return out
+
+
+def opencv_column(frames_np, gpu_flow, params, n):
+    """EPE and pairs/s against the REAL cv2.calcOpticalFlowFarneback, only if cv2 is importable on this box."""
+    try:
+        import cv2
+    except Exception:
+        return {"available": False}
+    es = []
+    t0 = time.perf_counter()
+    for i in range(n):
+        ref = cv2.calcOpticalFlowFarneback(frames_np[2 * i], frames_np[2 * i + 1], None, params["pyr_scale"], params["levels"],
+                                           params["winsize"], params["iterations"], params["poly_n"], params["poly_sigma"],
+                                           params["flags"])
+        es.append(np.linalg.norm(gpu_flow[i].astype(np.float64) - ref, axis=-1))
+    dt = time.perf_counter() - t0
+    e = np.concatenate([x.ravel() for x in es])
+    return {"available": True, "version": cv2.__version__, "pairs": n, "pairs_per_s": round(n / dt, 4),
+            "threads": cv2.getNumThreads(), "epe_mean": float(e.mean()), "epe_p999": float(np.quantile(e, 0.999)),
+            "epe_max": float(e.max())}
+
+
+def load_traffic(key):
+    tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        j = json.load(open(tj))
+    except Exception:
+        return {}
+    return j.get(key, j if key == "1080p_L5_I3" else {})
+
+
+def bench_latency(args, cfg, params):
+    """Config 2: one 1080p pair, host pointers in and out (the drop-in call), latency."""
+    import hackathonopticalflow_amd as ofa
+    from hackathonopticalflow_amd.synth import translated_pair, warped_pair
+    W, H = cfg["w"], cfg["h"]
+    if args.family == "warped":
+        prev, nxt, gt, _ = warped_pair(H, W, 2001, zoom=1.02, angle_deg=0.5)
+    else:
+        prev, nxt, shift = translated_pair(H, W, 2001)
+        gt = np.float32(shift)
+    eng = ofa.FarnebackEngine(W, H, 1, 0, **params)
+    flow = eng.calc(prev, nxt)
+    for _ in range(args.warmup):
+        eng.calc(prev, nxt, flow)
+    ts, dev = [], []
+    t_all = time.perf_counter()
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        flow = eng.calc(prev, nxt, flow)
+        ts.append((time.perf_counter() - t0) * 1e3)
+        dev.append(eng.last_device_ms)
+    t_all = time.perf_counter() - t_all
+    plan = ofa.level_plan(W, H, **params)
+    alg = algorithmic_bytes_per_pair(W, H, plan, params["iterations"])
+    dms = float(np.median(dev))
+    out = {
+        "metric": "latency of one 1920x1080 frame pair (5-level, 3-iter), host buffers in/out", "value": round(float(np.median(ts)), 4),
+        "unit": "ms", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t_all / args.steps * 1e3, 4),
+        "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"config2: one 1920x1080 {args.family} pair through ofarn_calc (host pointers: 4 MB in, 16.6 MB out over "
+                               f"PCIe inside the timed call), levels=5 iterations=3 winsize=15 poly_n=5", "global_pairs": 1},
+        "device_ms": round(dms, 4), "wall_ms_min": round(min(ts), 4), "pairs_per_s_wall": round(1e3 / float(np.median(ts)), 1),
+        "roofline": {"bound": "launch latency (about 40 short kernels, the three coarsest levels are a few thousand pixels)",
+                     "achieved": round(alg / (dms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_pair": alg},
+    }
+    if args.cpu_sample > 0:
+        from oracle import oracle as O
+        O.build()
+        t0 = time.perf_counter()
+        ref = O.farneback(prev, nxt, **params)
+        tc = time.perf_counter() - t0
+        e = np.linalg.norm(flow.astype(np.float64) - ref, axis=-1)
+        g = gt[None, None] if np.ndim(gt) == 1 else gt[32:-32, 32:-32]
+        out["cpu_baseline"] = {"value": round(tc * 1e3, 2), "unit": "ms", "cores": 1, "kind": "port",
+                               "sample": "the same pair, oracle/farneback_oracle.c on one thread (OpenCV's PolyExp / UpdateMatrices / "
+                                         "UpdateFlow loops are single-threaded scalar code)"}
+        out["mean_epe_vs_cpu_oracle_px"] = float(e.mean())
+        out["epe_vs_cpu_oracle"] = {"mean": float(e.mean()), "p999": float(np.quantile(e, 0.999)), "max": float(e.max())}
+        out["epe_vs_ground_truth_interior_px"] = float(np.linalg.norm(flow[32:-32, 32:-32] - g, axis=-1).mean())
+        out["opencv"] = opencv_column(np.stack([prev, nxt]), flow[None], params, 1)
+    print(json.dumps(out))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=512, help="frame pairs per GPU per step (config 3: 512)")
-    ap.add_argument("--wave", type=int, default=256, help="pairs resident per wave (ofarn max_batch); 256 pairs = 53 GB of workspace")
-    ap.add_argument("--unique", type=int, default=32, help="distinct synthetic pairs generated, then tiled")
-    ap.add_argument("--cpu-sample", type=int, default=16, help="pairs timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS), help="BASELINE.json config number (see the module docstring)")
+    ap.add_argument("--batch", type=int, default=None, help="override the config's pair count (per GPU for config 3, in total for 4 and 5)")
+    ap.add_argument("--wave", type=int, default=256, help="pairs resident per wave (ofarn max_batch)")
+    ap.add_argument("--unique", type=int, default=64, help="distinct synthetic pairs generated, then tiled")
+    ap.add_argument("--family", default="translated", choices=["translated", "warped"],
+                    help="synthetic input: integer translations (SURVEY 8(d)) or the FPV-like zoom + rotation + sub-pixel shift field")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="pairs timed on the CPU oracle (0 = skip); parity is reported on the first 16")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the CPU baseline (the GPU box's CPU share per GPU is 16)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel hipEvent timing")
     ap.add_argument("--prof-table", action="store_true", help="print per-(stage, level) timing rows to stderr")
     ap.add_argument("--no-two-stream", action="store_true",
                     help="skip the informational second measurement with per-kernel timing off (two internal streams)")
+    ap.add_argument("--no-family-check", action="store_true",
+                    help="skip the informational third measurement on the other input family (data-independence check)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (gloo: rehearsal of the multi-rank path with "
                          "several ranks sharing one GPU; the gather then goes through host memory)")
     args = ap.parse_args()
-    if args.steps < 1 or args.warmup < 0 or args.batch < 1 or args.wave < 1:
-        raise SystemExit("--steps and --batch and --wave must be >= 1, --warmup >= 0")
+    cfg = CONFIGS[args.config]
+    if args.steps is None:
+        args.steps = 20 if args.config == 2 else 5
+    if args.warmup is None:
+        args.warmup = 5 if args.config == 2 else 2
+    if args.steps < 1 or args.warmup < 0 or args.wave < 1 or (args.batch is not None and args.batch < 1):
+        raise SystemExit("--steps, --batch and --wave must be >= 1, --warmup >= 0")
 
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))      # fresh child; this process never initialises HIP
+    if env_world != max(args.gpus, 1):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env_world}")
+
+    params = dict(pyr_scale=0.5, levels=cfg["levels"], winsize=15, iterations=cfg["iterations"], poly_n=5, poly_sigma=1.2, flags=0)
     import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: hackathonopticalflow_amd has no CPU path")
+    if args.config == 2:
+        if args.gpus != 1:
+            raise SystemExit("config 2 is a single pair on a single GPU")
+        return bench_latency(args, cfg, params)
+
     import hackathonopticalflow_amd as ofa
     from hackathonopticalflow_amd import distributed as D
 
     rank, local_rank, world = D.env_rank_world()
-    if world != max(args.gpus, 1):
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: hackathonopticalflow_amd has no CPU path")
-    dev_index = local_rank % torch.cuda.device_count()
+    W, H = cfg["w"], cfg["h"]
+    dev_index = local_rank % torch.cuda.device_count()     # gloo rehearsal: several ranks share the one GPU of the box
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = D.init_process_group(args.backend) if world > 1 else None
 
-    B = args.batch
-    eng = ofa.FarnebackEngine(W, H, min(args.wave, B), dev_index, **PARAMS)
+    # pairs: config 3 = a fixed batch per GPU (weak); configs 4, 5 = a fixed global batch sharded over the ranks (strong)
+    if "per_gpu_pairs" in cfg:
+        B = args.batch or cfg["per_gpu_pairs"]
+        global_pairs, pair_start = B * world, rank * B
+    else:
+        global_pairs = args.batch or cfg["global_pairs"]
+        pair_start, B = D.shard_pairs(global_pairs, rank, world)
+        if B < 1:
+            raise SystemExit(f"{global_pairs} pairs cannot be sharded over {world} ranks")
+    wave = min(args.wave, B)
+    eng = ofa.FarnebackEngine(W, H, wave, dev_index, **params)
     P = len(ofa.grid_points(W, H, 30))
-    plan = ofa.level_plan(W, H, **PARAMS)
+    plan = ofa.level_plan(W, H, **params)
 
-    # synthetic input, resident in HBM before anything is timed
-    uniq = min(args.unique, B)
-    fr_u, shifts = make_frames_gpu(torch, uniq, 3000 + rank * B, device)
-    frames = torch.empty((2 * B, H, W), dtype=torch.uint8, device=device)
-    for i in range(B):
-        frames[2 * i:2 * i + 2] = fr_u[2 * (i % uniq):2 * (i % uniq) + 2]
+    # synthetic input, resident in HBM before anything is timed; global pair g uses distinct pair g % unique
+    uniq = min(args.unique, global_pairs)
+    fr_u, gt_u = make_frames_gpu(torch, uniq, 3000, device, W, H, args.family)
+
+    def tile(fr):
+        frames = torch.empty((2 * B, H, W), dtype=torch.uint8, device=device)
+        for i in range(B):
+            j = (pair_start + i) % uniq
+            frames[2 * i:2 * i + 2] = fr[2 * j:2 * j + 2]
+        return frames
+
+    frames = tile(fr_u)
     flow = torch.empty((B, H, W, 2), dtype=torch.float32, device=device)
     mask = torch.zeros((B, P), dtype=torch.uint8, device=device)
     v = torch.zeros((B, P), dtype=torch.uint8, device=device)
     stream = torch.cuda.current_stream().cuda_stream
+    gathered = [None]
 
     def step():
         eng.calc_batch_device(frames, 2 * B, W, H, ofa.PAIRS_INDEPENDENT, flow, mask, v, stream=stream)
         if dist is not None:
             if args.backend == "gloo":
-                return D.gather_danger_maps(mask.cpu(), v.cpu(), B * world, dist)
-            return D.gather_danger_maps(mask, v, B * world, dist)
-        return mask, v
+                gathered[0] = D.gather_danger_maps(mask.cpu(), v.cpu(), global_pairs, dist)
+            else:
+                gathered[0] = D.gather_danger_maps(mask, v, global_pairs, dist)
 
     def fence():
         torch.cuda.synchronize()
@@ -185,41 +391,72 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed_steps(k):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        fence()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
     for _ in range(args.warmup):
         step()
     fence()
     if not args.no_profile:
         eng.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_steps(args.steps)
     prof = [] if args.no_profile else eng.profile_read()
     eng.profile_enable(False)
+
+    # the gather really gathered: every rank finds its own shard at its place in the global arrays
+    gather_ok = None
+    if dist is not None:
+        gm, gv = gathered[0]
+        ok = (gm.shape == (global_pairs, P) and bool((gm[pair_start:pair_start + B].to(mask.device) == mask).all())
+              and bool((gv[pair_start:pair_start + B].to(v.device) == v).all()))
+        t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        gather_ok = bool(t.item())
 
     # Informational second measurement (never `value`): the same K steps with per-kernel timing off.  The library then
     # alternates the waves of a batch over two internal streams, so the VALU-bound stages of one wave overlap the HBM-bound
     # iterations of the other; per-kernel durations lose their meaning there, which is why the timed region above keeps
     # everything on one stream.
     overlapped = None
-    if not args.no_profile and not args.no_two_stream and min(args.wave, B) < B:
+    if not args.no_profile and not args.no_two_stream and wave < B:
         step()
+        overlapped = global_pairs * args.steps / timed_steps(args.steps)
+
+    # Informational third measurement (never `value`): the same K steps on the OTHER input family.  The one data-dependent
+    # part of the pipeline is the bilinear gather of FarnebackUpdateMatrices (address pattern and its out-of-image branch).
+    other = None
+    if not args.no_family_check and world == 1:
+        other_family = "warped" if args.family == "translated" else "translated"
+        u2 = min(8, uniq)
+        fr_o, _ = make_frames_gpu(torch, u2, 7000, device, W, H, other_family)
+        keep = frames
+        frames = torch.empty_like(keep)
+        for i in range(B):
+            frames[2 * i:2 * i + 2] = fr_o[2 * (i % u2):2 * (i % u2) + 2]
+        step()
+        if not args.no_profile:
+            eng.profile_enable(True)
+        e3 = timed_steps(args.steps)
+        prof_o = [] if args.no_profile else eng.profile_read()
+        eng.profile_enable(False)
+        other = {"family": other_family, "pairs_per_s": round(global_pairs * args.steps / e3, 2)}
+        fi = [r for r in prof_o if r["stage"] == "flow_iter" and r["level"] == 0]
+        if fi:
+            other["flow_iter_level0_avg_ms"] = round(fi[0]["ms"] / fi[0]["launches"], 4)
+        frames = keep
+        del fr_o
+        step()          # leave flow / mask of the primary family in the buffers for the parity report
         fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        e2 = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([e2], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e2 = float(t.item())
-        overlapped = B * world * args.steps / e2
 
     if rank != 0:
         if dist is not None:
@@ -233,9 +470,10 @@ def main():
             gbs = STAGE_BYTES.get(r["stage"], 0.0) * r["units"] / r["launches"] / (per * 1e-3) / 1e9
             print(f"  {r['stage']:16s} L{r['level']} launches={r['launches']:4d} total={r['ms']:9.3f} ms "
                   f"avg={per:8.4f} ms  alg={gbs:8.1f} GB/s", file=sys.stderr)
-    pairs_total = B * world * args.steps
+    pairs_total = global_pairs * args.steps
     value = pairs_total / elapsed
-    alg_pair = algorithmic_bytes_per_pair(W, H, plan, PARAMS["iterations"])
+    alg_pair = algorithmic_bytes_per_pair(W, H, plan, params["iterations"])
+    traffic_tab = load_traffic(cfg["key"])
 
     roofline = None
     if prof:
@@ -247,18 +485,15 @@ def main():
         # MI355X_MICROARCH.md prescribes; provenance inside profiles/pmc_traffic.json), measured per work unit at
         # level 0 and scaled to this run's units per launch.
         traffic = None
-        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tj) and dom["level"] == 0:
-            try:
-                per_unit = json.load(open(tj)).get(dom["stage"], {}).get("hbm_bytes_per_unit")
-                if per_unit:
-                    traffic = per_unit * dom["units"] / dom["launches"]
-            except Exception:
-                traffic = None
+        per_unit = (traffic_tab.get(dom["stage"]) or {}).get("hbm_bytes_per_unit") if dom["level"] == 0 else None
+        if per_unit:
+            traffic = per_unit * dom["units"] / dom["launches"]
         total_ms = sum(r["ms"] for r in prof)
+        real_pair = traffic_tab.get("pipeline_hbm_bytes_per_pair")
         roofline = {
             "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_frac": round(traffic / per_launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
             "kernel": f"{dom['stage']}@level{dom['level']}",
             "kernel_avg_ms": round(per_launch_s * 1e3, 4), "kernel_launches": dom["launches"],
             "kernel_share_of_device_time": round(dom["ms"] / total_ms, 4),
@@ -267,6 +502,8 @@ def main():
                 "algorithmic_bytes_per_pair": alg_pair,
                 "achieved": round(alg_pair * value / world / 1e9, 1),
                 "frac": round(alg_pair * value / world / 1e9 / HBM_PEAK_GBS, 4),
+                "real_bytes_per_pair": real_pair,
+                "real_frac": round(real_pair * value / world / 1e9 / HBM_PEAK_GBS, 4) if real_pair else None,
             },
             "stages_ms_per_step": {},
         }
@@ -275,31 +512,44 @@ def main():
             agg[r["stage"]] = agg.get(r["stage"], 0.0) + r["ms"] / args.steps
         roofline["stages_ms_per_step"] = {k: round(val, 3) for k, val in agg.items()}
 
+    res = "1920x1080" if W == 1920 else f"{W}x{H}"
+    if args.config == 3:
+        workload = f"config3: {res} batch={B} {args.family} smooth-noise pairs per GPU"
+    else:
+        workload = f"config{args.config}: {res} batch={global_pairs} {args.family} smooth-noise pairs in total, {B} per GPU (sharded)"
     out = {
-        "metric": "frame-pairs/s @1080p (5-level, 3-iter)", "value": round(value, 2), "unit": "pairs/s",
+        "metric": f"frame-pairs/s @{'1080p' if W == 1920 else '4K'} ({cfg['levels']}-level, {cfg['iterations']}-iter)",
+        "value": round(value, 2), "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": cfg["scaling"],
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"config3: 1920x1080 batch={B} translated smooth-noise pairs per GPU "
-                               f"({uniq} distinct, tiled), levels=5 iterations=3 winsize=15 poly_n=5, f32 with OpenCV's f64 "
-                               f"accumulators, "
-                               f"flow + danger maps to HBM" + (", RCCL all-gather of danger maps" if world > 1 else ""),
-                   "pairs_per_gpu": B, "global_pairs": B * world, "wave": min(args.wave, B),
+        "config": {"workload": workload + f" ({uniq} distinct, tiled), levels={cfg['levels']} iterations={cfg['iterations']} winsize=15 "
+                               f"poly_n=5, f32 with OpenCV's f64 accumulators, flow + danger maps to HBM"
+                               + (f", {args.backend} all-gather of danger maps" if world > 1 else ""),
+                   "pairs_per_gpu": B, "global_pairs": global_pairs, "wave": wave,
+                   "workspace_bytes_per_gpu": eng.workspace_bytes,
                    "parallelism": f"pairs sharded over {world} GPU(s)"},
         "roofline": roofline,
     }
+    if gather_ok is not None:
+        out["gathered_danger_maps_checked"] = gather_ok
     if overlapped is not None:
         out["two_stream_pairs_per_s"] = round(overlapped, 2)   # per-kernel timing off: waves overlap on two streams (informational)
+    if other is not None:
+        out["other_family"] = other
     if world == 1 and args.cpu_sample > 0:
-        ns = min(args.cpu_sample, uniq)
-        cb, epe, gt = cpu_baseline(fr_u[:2 * ns].cpu().numpy(), flow[:ns].cpu().numpy(), ns, shifts)
+        ns = min(args.cpu_sample, uniq, B)
+        npar = min(16, ns)
+        fr_np = fr_u[:2 * ns].cpu().numpy()
+        cb, ref = cpu_baseline(fr_np, ns, params, args.cpu_threads)
         out["cpu_baseline"] = cb
-        out["mean_epe_vs_cpu_oracle_px"] = epe["mean"]
-        out["epe_vs_cpu_oracle"] = epe
-        if gt:
-            out["epe_vs_ground_truth_interior_px"] = gt
-        out["speedup_vs_cpu_all_cores"] = round(value / cb["value"], 1)
-        out["speedup_vs_cpu_1thread"] = round(value / cb["single_thread_value"], 1)
+        par = parity_report(ofa, flow[:npar].cpu().numpy(), mask[:npar].cpu().numpy(), ref[:npar],
+                            [gt_u[i] for i in range(npar)], W, H, args.family)
+        par["opencv"] = opencv_column(fr_np, flow[:min(npar, 4)].cpu().numpy(), params, min(npar, 4))
+        out["parity"] = par
+        out["mean_epe_vs_cpu_oracle_px"] = par["epe_vs_cpu_oracle"]["mean"]
+        out[f"speedup_vs_cpu_{cb['cores']}_threads"] = round(value / cb["value"], 1)
+        out["speedup_vs_cpu_1_thread"] = round(value / cb["single_thread_value"], 1)
     print(json.dumps(out))
     if dist is not None:
         dist.barrier()

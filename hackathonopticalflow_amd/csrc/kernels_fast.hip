@@ -957,12 +957,16 @@ namespace ofarn {
 // GPU holds blocks_per_cu * CUs blocks at once; minimise ceil(blocks / resident) * rows-per-block.
 int best_strip_units(int nunits, int unit, int warm, int blocks_per_strip_row, int blocks_per_cu)
 {
-    static int ncu = 0;
+    // CU count of the CURRENT device, cached per device ordinal (a process may drive several GPUs)
+    static int ncu_of[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int ncu = __atomic_load_n(&ncu_of[dev], __ATOMIC_RELAXED);
     if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        ncu = v;
+        __atomic_store_n(&ncu_of[dev], v, __ATOMIC_RELAXED);
     }
     const long resident = (long)ncu * blocks_per_cu;
     long best_cost = -1;

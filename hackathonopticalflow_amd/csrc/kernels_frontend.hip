@@ -125,8 +125,9 @@ void launch_resize_area(hipStream_t s, const float *src, int sw, int sh, float *
 //   ang = arctan2(fy, fx) + pi; v = sqrt(fx*fx + fy*fy)               float32 (NumPy 2 promotion)
 //   H = uint8(ang * (180/pi/2)); S = 255; V = uint8(minimum(v*4, 255))  truncating stores
 //   bgr = cvtColor(hsv, COLOR_HSV2BGR)                                 color_hsv.simd.hpp HSV2RGB_b
-// atan2f is the one transcendental here; a last-ulp difference from the host libm can move H by one
-// at a truncation boundary (tests allow that on the HSV plane and check HSV -> BGR bit for bit).
+// arctan2 is the one transcendental here.  NumPy's float32 arctan2 is a SIMD approximation (up to 3.2 ulp on this
+// container's build, CPU dependent), so the contract is the correctly rounded float32 value: evaluated in double and
+// rounded once, as oracle/frontend_oracle.c does; the measured agreement with NumPy is in tests/test_gpu_parity.py.
 __device__ __forceinline__ uint8_t sat_round_u8(float v)
 {
     const float r = rintf(v);   // cvRound: half to even
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void k_flow_hsv(const float2 *__restrict__ flo
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= npx) return;
     const float2 f = flow[i];
-    const float ang = atan2f(f.y, f.x) + 3.14159274101257324f;           // float32(np.pi)
+    const float ang = (float)atan2((double)f.y, (double)f.x) + 3.14159274101257324f;   // correctly rounded arctan2 + float32(np.pi)
     const float v = sqrtf(f.x * f.x + f.y * f.y);
     const uint8_t H = (uint8_t)(int)(ang * 28.6478900909423828f);        // float32(180/np.pi/2)
     const uint8_t V = (uint8_t)(int)fminf(v * 4.f, 255.f);

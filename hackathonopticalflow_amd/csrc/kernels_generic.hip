@@ -346,68 +346,106 @@ __global__ __launch_bounds__(256) void k_gauss_solve(const float *__restrict__ M
 // ---------------------------------------------------------------------------------------------
 // Stage F.  Sample flow[y][x] at the measurement grid (DenseOF.py:44-45), the vector filter of
 // pathfinder_viewer.py:159-176 and the V value of pathfinder_viewer.py:204-217.
-// One block per pair.  The equalised moduli are bitonic-sorted in LDS to read the order
-// statistics np.median / np.percentile(…, 99) need; all threshold arithmetic is float32, in
-// NumPy's order (see oracle/filter_oracle.c).
+// One block per pair, any number of grid points P.  np.median / np.percentile(..., 99) need four order
+// statistics of the equalised moduli; they are found with a most-significant-digit radix SELECT on the float
+// bit patterns (the moduli are >= 0, so unsigned order is float order): four passes of 8 bits, a 256-bin
+// histogram per wanted rank in LDS, the moduli recomputed from the flow on every pass -- no P-sized buffer,
+// so a dense grid (step 5 at 1080p: 82 944 points) costs nothing but passes.  All threshold arithmetic is
+// float32 in NumPy's order (oracle/filter_oracle.c).  A NaN modulus makes median and percentile NaN, as in NumPy.
+//
+// arctan2 / cos / sin: NumPy's float32 loops are SIMD approximations (measured on this container's build: up to
+// 3.2 ulp for arctan2, 1.4 ulp for cos) whose last bits differ between CPUs, so there is no single "NumPy value".
+// The contract here is the correctly rounded float32 result: evaluated in double, rounded once
+// (oracle/filter_oracle.c does the same with the host libm); see tests/test_gpu_parity.py for the measured
+// agreement with this container's NumPy.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+__device__ __forceinline__ float cr_atan2f(float y, float x) { return (float)atan2((double)y, (double)x); }
+__device__ __forceinline__ float cr_cosf(float a) { return (float)cos((double)a); }
+__device__ __forceinline__ float cr_sinf(float a) { return (float)sin((double)a); }
+
+__device__ __forceinline__ float grid_modulus(const float2 d, const int2 p, float hw, float hh)
+{
+    const float mod = sqrtf(d.x * d.x + d.y * d.y);
+    const float ddx = hw - (float)p.x, ddy = hh - (float)p.y;
+    const float mm = sqrtf(ddx * ddx + ddy * ddy);
+    return __fdiv_rn(mod, 5.0f + sqrtf(mm)) * 30.0f;
+}
 
 __global__ __launch_bounds__(1024) void k_grid_filter(const float2 *__restrict__ flow, int w, int h,
-                                                       const int2 *__restrict__ pts, int P, int P2, int variant,
+                                                       const int2 *__restrict__ pts, int P, int variant,
                                                        uint8_t *__restrict__ mask, uint8_t *__restrict__ v,
                                                        int *__restrict__ iflow, const float2 *__restrict__ vecs)
 {
-    extern __shared__ float smem[];
-    float *srt = smem;          // [P2]
+    __shared__ unsigned s_hist[4][256];
+    __shared__ unsigned s_prefix[4], s_rank[4];
+    __shared__ int s_nan;
     __shared__ float s_thr[2];
     const int tid = threadIdx.x, nt = blockDim.x;
     // vectors at the grid points: sampled from the dense flow (DenseOF.py:44-45), or given (LK: next_pts - points_)
     const float2 *f = flow ? flow + (size_t)blockIdx.x * w * h : nullptr;
     const float2 *vp = vecs ? vecs + (size_t)blockIdx.x * P : nullptr;
     const float hw = (float)(w / 2), hh = (float)(h / 2);
+    auto modulus_at = [&](int i) {
+        const int2 p = pts[i];
+        const float2 d = vp ? vp[i] : f[(size_t)p.y * w + p.x];
+        return grid_modulus(d, p, hw, hh);
+    };
 
-    for (int i = tid; i < P2; i += nt) {
-        float mval = __builtin_inff();
-        if (i < P) {
-            const int2 p = pts[i];
-            const float2 d = vp ? vp[i] : f[(size_t)p.y * w + p.x];
-            const float mod = sqrtf(d.x * d.x + d.y * d.y);
-            const float ddx = hw - (float)p.x, ddy = hh - (float)p.y;
-            const float mm = sqrtf(ddx * ddx + ddy * ddy);
-            mval = __fdiv_rn(mod, 5.0f + sqrtf(mm)) * 30.0f;
-        }
-        srt[i] = mval;
+    // ranks (0-based, ascending) of the order statistics: the two middles of the median, the two neighbours of the
+    // 99-percentile's virtual index (numpy _function_base_impl.py: float32 arithmetic for float32 data)
+    const float quant = 99.0f / 100.0f;
+    const float vi = (float)(P - 1) * quant;
+    const float prevf = floorf(vi);
+    int pi = (int)prevf, ni = pi + 1;
+    if (vi >= (float)(P - 1)) { pi = P - 1; ni = P - 1; }
+    if (ni > P - 1) ni = P - 1;
+    if (tid < 4) {
+        const int r[4] = {(P & 1) ? P / 2 : P / 2 - 1, P / 2, pi, ni};
+        s_rank[tid] = (unsigned)r[tid];
+        s_prefix[tid] = 0u;
     }
-    __syncthreads();
-    for (int k = 2; k <= P2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < P2; i += nt) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const float a = srt[i], b = srt[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { srt[i] = b; srt[ixj] = a; }
-                }
-            }
-            __syncthreads();
+    if (tid == 0) s_nan = 0;
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = 24 - 8 * pass;
+        for (int i = tid; i < 4 * 256; i += nt) (&s_hist[0][0])[i] = 0u;
+        __syncthreads();
+        const unsigned himask = pass == 0 ? 0u : 0xFFFFFFFFu << (shift + 8);
+        const unsigned p0 = s_prefix[0], p1 = s_prefix[1], p2 = s_prefix[2], p3 = s_prefix[3];
+        for (int i = tid; i < P; i += nt) {
+            const float m = modulus_at(i);
+            if (m != m) { if (pass == 0) s_nan = 1; continue; }
+            const unsigned u = __float_as_uint(m);
+            const unsigned hi = u & himask, dg = (u >> shift) & 255u;
+            if (hi == p0) atomicAdd(&s_hist[0][dg], 1u);
+            if (hi == p1) atomicAdd(&s_hist[1][dg], 1u);
+            if (hi == p2) atomicAdd(&s_hist[2][dg], 1u);
+            if (hi == p3) atomicAdd(&s_hist[3][dg], 1u);
         }
+        __syncthreads();
+        if (tid < 4) {
+            unsigned r = s_rank[tid], acc = 0;
+            int d = 0;
+            for (; d < 255; d++) {
+                const unsigned cnt = s_hist[tid][d];
+                if (acc + cnt > r) break;
+                acc += cnt;
+            }
+            s_rank[tid] = r - acc;
+            s_prefix[tid] |= (unsigned)d << shift;
+        }
+        __syncthreads();
     }
     if (tid == 0) {
-        float med;
-        if (P & 1) med = srt[P / 2];
-        else med = (srt[P / 2 - 1] + srt[P / 2]) / 2.0f;
+        const float m0 = __uint_as_float(s_prefix[0]), m1 = __uint_as_float(s_prefix[1]);
+        float med = (P & 1) ? m1 : (m0 + m1) / 2.0f;
         med = med * 1.0f;
-        const float quant = 99.0f / 100.0f;
-        const float vi = (float)(P - 1) * quant;
-        const float prevf = floorf(vi);
-        int pi = (int)prevf, ni = pi + 1;
-        if (vi >= (float)(P - 1)) { pi = P - 1; ni = P - 1; }
-        if (ni > P - 1) ni = P - 1;
         const float t = vi - prevf;
-        const float a = srt[pi], b = srt[ni];
+        const float a = __uint_as_float(s_prefix[2]), b = __uint_as_float(s_prefix[3]);
         const float diff = b - a;
+        float p99 = (t >= 0.5f) ? b - diff * (1.0f - t) : a + diff * t;
+        if (s_nan) { med = __builtin_nanf(""); p99 = med; }
         s_thr[0] = med;
-        s_thr[1] = (t >= 0.5f) ? b - diff * (1.0f - t) : a + diff * t;
+        s_thr[1] = p99;
     }
     __syncthreads();
     const float med = s_thr[0], p99 = s_thr[1];
@@ -415,17 +453,14 @@ __global__ __launch_bounds__(1024) void k_grid_filter(const float2 *__restrict__
         const int2 p = pts[i];
         const float2 d = vp ? vp[i] : f[(size_t)p.y * w + p.x];
         const float x = (float)p.x, y = (float)p.y;
-        const float mod0 = sqrtf(d.x * d.x + d.y * d.y);
-        const float ddx = hw - x, ddy = hh - y;
-        const float mm = sqrtf(ddx * ddx + ddy * ddy);
-        const float mod = __fdiv_rn(mod0, 5.0f + sqrtf(mm)) * 30.0f;
+        const float mod = grid_modulus(d, p, hw, hh);
         // variant 0: pathfinder_viewer.py:173  (median*1.0 < mod) & (mod < P99)
         // variant 1: DenseOF.py:228            mod > median*1.2   (float32 product)
         const bool keep = variant == 1 ? (mod > med * 1.2f) : ((med < mod) && (mod < p99));
         uint8_t val = 0;
         if (keep || iflow) {
-            const float ang = atan2f(d.y, d.x);
-            const float gx = mod * cosf(ang), gy = mod * sinf(ang);
+            const float ang = cr_atan2f(d.y, d.x);
+            const float gx = mod * cr_cosf(ang), gy = mod * cr_sinf(ang);
             const int nx = (int)((x + gx) + 0.5f), ny = (int)((y + gy) + 0.5f);
             const int px = (int)(x + 0.5f), py = (int)(y + 0.5f);
             const int a = nx - px, b = ny - py;
@@ -433,11 +468,11 @@ __global__ __launch_bounds__(1024) void k_grid_filter(const float2 *__restrict__
                 iflow[((size_t)blockIdx.x * P + i) * 2] = a;
                 iflow[((size_t)blockIdx.x * P + i) * 2 + 1] = b;
             }
-          if (keep) {
-            double vv = 50.0 + sqrt((double)(a * a + b * b)) * 2.0;
-            if (vv > 255.0) vv = 255.0;
-            val = (uint8_t)vv;
-          }
+            if (keep) {
+                double vv = 50.0 + sqrt((double)(a * a + b * b)) * 2.0;
+                if (vv > 255.0) vv = 255.0;
+                val = (uint8_t)vv;
+            }
         }
         mask[(size_t)blockIdx.x * P + i] = keep ? 1 : 0;
         v[(size_t)blockIdx.x * P + i] = val;
@@ -498,12 +533,9 @@ void launch_blur_solve(hipStream_t s, const float *M, float *flow, int w, int h,
     int TW = 64;
     while (TW > 8 && (TW * B > 256 * BS_MAXOUT || (size_t)B * (TW + 2 * m) * 8 > 150 * 1024)) TW >>= 1;
     const size_t lds = sizeof(double) * (size_t)B * (TW + 2 * m);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_blur_solve),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    // the attribute belongs to the (function, device) pair: set it on every launch of this unfused path rather than
+    // cache a per-process flag that would be wrong on a second GPU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_blur_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const double scale = 1. / ((double)winsize * winsize);
     dim3 grid(cdiv(w, TW), cdiv(h, B), npairs);
     hipLaunchKernelGGL(k_blur_solve, grid, dim3(256), lds, s, M, reinterpret_cast<float2 *>(flow), w, h, m, TW,
@@ -516,31 +548,18 @@ void launch_gauss_solve(hipStream_t s, const float *M, float *flow, int w, int h
     const int m = winsize / 2;
     const int IW = GS_TW + 2 * m, IH = GS_TH + 2 * m;
     const size_t lds = sizeof(float) * (size_t)(IH * IW + GS_TH * IW + m + 1);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gauss_solve),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gauss_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     dim3 grid(cdiv(w, GS_TW), cdiv(h, GS_TH), npairs);
     hipLaunchKernelGGL(k_gauss_solve, grid, dim3(256), lds, s, M, reinterpret_cast<float2 *>(flow), w, h, m, d_kern);
-}
-
-int grid_filter_lds_bytes(int P)
-{
-    int p2 = 1;
-    while (p2 < P) p2 <<= 1;
-    return p2 * (int)sizeof(float);
 }
 
 void launch_grid_filter(hipStream_t s, const float *flow, int w, int h, int npairs, const int *d_pts, int P,
                         int variant, uint8_t *mask, uint8_t *v, int32_t *iflow, const float *vecs)
 {
-    int p2 = 1;
-    while (p2 < P) p2 <<= 1;
-    hipLaunchKernelGGL(k_grid_filter, dim3(npairs), dim3(1024), (size_t)p2 * sizeof(float), s,
+    if (npairs <= 0 || P <= 0) return;
+    hipLaunchKernelGGL(k_grid_filter, dim3(npairs), dim3(P >= 4096 ? 1024 : 256), 0, s,
                        reinterpret_cast<const float2 *>(flow), w, h, reinterpret_cast<const int2 *>(d_pts), P,
-                       p2, variant, mask, v, iflow, reinterpret_cast<const float2 *>(vecs));
+                       variant, mask, v, iflow, reinterpret_cast<const float2 *>(vecs));
 }
 
 }  // namespace ofarn

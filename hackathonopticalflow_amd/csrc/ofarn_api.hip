@@ -319,7 +319,7 @@ hipEvent_t prof_event(ofarn_ctx *c)
 {
     if (!c->prof_free.empty()) { hipEvent_t e = c->prof_free.back(); c->prof_free.pop_back(); return e; }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return e;
 }
 
@@ -338,47 +338,64 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
     int pw = 0, ph = 0;
     const bool gauss = (c->prm.flags & OFARN_FLAG_FARNEBACK_GAUSSIAN) != 0;
     const bool fused = !c->force_generic && !gauss && c->prm.iterations >= 1 && flow_iter_supported(c->prm.winsize);
-    // Row pass of the level build for all levels that need one, in a single launch when their
-    // tmp buffers fit side by side in the workspace; tmp_of[k] is where level k's rows went.
+    // Row pass of the level build for all levels that need one, in a single launch; tmp_of[k] is where level k's
+    // rows go.  The plan is made first (offsets only), then the workspace is grown to what it needs.
     const bool march0 = !c->force_generic && polyexp_march_supported(c->prm.poly_n);
     float *tmp_of[32] = {nullptr};
-    bool hdirect[32] = {false};
-    if (!c->force_generic) {
-        HLevels HL{};
-        size_t off = 0;
-        bool ok = true;
-        for (int k = nlev; k >= 0 && ok; k--) {
+    size_t tmp_off[32] = {0};
+    bool has_tmp[32] = {false}, hdirect[32] = {false};
+    int hl_level[12] = {0};
+    HLevels HL{};
+    size_t tmp_need = 0, I_need = 0;
+    bool multi = false;
+    {
+        size_t off = 0, single = 0;
+        bool ok = !c->force_generic;
+        for (int k = nlev; k >= 0; k--) {
             const Level &L = c->lv[k];
-            if (march0 && L.w == w && L.h == h && L.ksize == 3) continue;   // fused into the poly expansion
-            if (nframes >= c->direct_min_frames && level_direct_supported(d_frames, w, h, L.w, L.h, L.ksize))
+            if (march0 && L.w == w && L.h == h && L.ksize == 3) continue;   // fused into the poly expansion, no level image
+            I_need = std::max(I_need, (size_t)nframes * L.w * L.h);
+            if (!c->force_generic && nframes >= c->direct_min_frames && level_direct_supported(d_frames, w, h, L.w, L.h, L.ksize))
                 continue;   // built by k_level_direct, no tmp
             const size_t need = (size_t)nframes * h * L.w * 2;
-            if (HL.n >= 12 || off + need > c->tmp_floats) { ok = false; break; }
+            single = std::max(single, need);
+            if (!ok) continue;
             if (nframes >= c->direct_min_frames && level_hdirect_supported(d_frames, w, L.w, L.ksize))
                 hdirect[k] = true;   // 1/16, 1/32, 1/64 widths: row pass straight from the frames, no LDS staging
+            else if (HL.n >= 12) { ok = false; continue; }
             else {
-                HL.lv[HL.n++] = HLevel{L.d_kern, L.d_xofs, ws.tmp + off, L.w, L.ksize};
+                hl_level[HL.n] = k;
+                HL.lv[HL.n++] = HLevel{L.d_kern, L.d_xofs, nullptr, L.w, L.ksize};
                 if (L.ksize / 2 > HL.rmax) HL.rmax = L.ksize / 2;
             }
-            tmp_of[k] = ws.tmp + off;
+            has_tmp[k] = true;
+            tmp_off[k] = off;
             off += need;
         }
         HL.rmax = (HL.rmax + 3) & ~3;   // border width in LDS: a multiple of 4 keeps the 16-byte staging writes aligned
-        if (ok && (HL.n == 0 || hpass_multi_lds_bytes(w, HL.rmax) <= 60 * 1024)) {
-            if (HL.n > 0) {
-                double units = 0;
-                for (int i = 0; i < HL.n; i++) units += (double)HL.lv[i].dw * h * nframes;
-                timed(c, s, OFARN_STAGE_LEVEL_H, 31, units, [&] { launch_level_hpass_multi(s, d_frames, fsz, w, h, nframes, HL); });
+        multi = ok && (HL.n == 0 || hpass_multi_lds_bytes(w, HL.rmax) <= 60 * 1024);
+        tmp_need = multi ? off : single;
+    }
+    {
+        const size_t M_need = fused ? 0 : (size_t)npairs * fsz * 5;   // the fused iteration kernel keeps M on chip
+        int rc = ws_reserve(c, wi, tmp_need, I_need, 0, M_need, 0);
+        if (rc) return rc;
+    }
+    if (multi) {
+        for (int k = 0; k <= nlev; k++) if (has_tmp[k]) tmp_of[k] = ws.tmp + tmp_off[k];
+        for (int i = 0; i < HL.n; i++) HL.lv[i].dst = tmp_of[hl_level[i]];
+        if (HL.n > 0) {
+            double units = 0;
+            for (int i = 0; i < HL.n; i++) units += (double)HL.lv[i].dw * h * nframes;
+            timed(c, s, OFARN_STAGE_LEVEL_H, 31, units, [&] { launch_level_hpass_multi(s, d_frames, fsz, w, h, nframes, HL); });
+        }
+        for (int k = nlev; k >= 0; k--)
+            if (hdirect[k]) {
+                const Level &L = c->lv[k];
+                timed(c, s, OFARN_STAGE_LEVEL_H, k, (double)L.w * h * nframes, [&] {
+                    launch_level_hdirect(s, d_frames, fsz, w, h, nframes, L.h_kern.data(), L.ksize, tmp_of[k], L.w);
+                });
             }
-            for (int k = nlev; k >= 0; k--)
-                if (hdirect[k]) {
-                    const Level &L = c->lv[k];
-                    timed(c, s, OFARN_STAGE_LEVEL_H, k, (double)L.w * h * nframes, [&] {
-                        launch_level_hdirect(s, d_frames, fsz, w, h, nframes, L.h_kern.data(), L.ksize, tmp_of[k], L.w);
-                    });
-                }
-        } else
-            for (auto &t : tmp_of) t = nullptr;
     }
     // OPTFLOW_USE_INITIAL_FLOW: the coarsest level starts from resize(flow0, INTER_AREA) * scale instead of zero
     const float *init_cur = nullptr;
@@ -516,26 +533,44 @@ int ensure_staging(ofarn_ctx *c, size_t frames_bytes, size_t flow_bytes, size_t 
     return OFARN_OK;
 }
 
-// Allocates workspace `wi` for max_batch pairs at max_w x max_h.  Returns 0 on success.
-int alloc_workspace(ofarn_ctx *c, int wi)
+// Grow-only reservation (sizes in floats; 0 = leave alone).  Growing frees the old buffer first, which waits for
+// the device: it happens on the first call of a shape, not per call.
+int ws_reserve(ofarn_ctx *c, int wi, size_t tmp, size_t I, size_t R, size_t M, size_t flow)
 {
     ofarn_ctx::Workspace &ws = c->ws[wi];
-    if (ws.tmp) return 0;
+    auto grow = [&](float **p, size_t *cap, size_t need, const char *what) -> int {
+        if (need <= *cap) return OFARN_OK;
+        if (*p) { (void)hipFree(*p); c->ws_bytes -= *cap * sizeof(float) + 256; *p = nullptr; *cap = 0; }
+        const size_t bytes = need * sizeof(float) + 256;
+        if (hipMalloc((void **)p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            *p = nullptr;
+            return fail(OFARN_E_NOMEM, "workspace buffer %s of %zu bytes does not fit (max_batch=%d at %dx%d)", what, bytes,
+                        c->max_batch, c->max_w, c->max_h);
+        }
+        *cap = need;
+        c->ws_bytes += bytes;
+        return OFARN_OK;
+    };
+    int rc;
+    if ((rc = grow(&ws.tmp, &ws.cap_tmp, tmp, "tmp")) || (rc = grow(&ws.I, &ws.cap_I, I, "I")) ||
+        (rc = grow(&ws.R, &ws.cap_R, R, "R")) || (rc = grow(&ws.M, &ws.cap_M, M, "M")))
+        return rc;
+    if (flow > ws.cap_flow) {
+        size_t cap = ws.cap_flow;
+        if ((rc = grow(&ws.flowA, &cap, flow, "flowA"))) return rc;
+        if ((rc = grow(&ws.flowB, &ws.cap_flow, flow, "flowB"))) return rc;
+    }
+    return OFARN_OK;
+}
+
+// Workspace `wi` for max_batch pairs at max_w x max_h: R and the two flow buffers now, the rest on demand.
+// Returns 0 on success.
+int alloc_workspace(ofarn_ctx *c, int wi)
+{
     const size_t px = (size_t)c->max_w * c->max_h;
     const size_t F = (size_t)2 * c->max_batch, Pn = (size_t)c->max_batch;
-    struct { float **p; size_t n; } req[] = {
-        {&ws.tmp, F * px * 2}, {&ws.I, F * px}, {&ws.R, F * (px * 5 + 4)}, {&ws.M, Pn * px * 5},
-        {&ws.flowA, Pn * px * 2}, {&ws.flowB, Pn * px * 2}};
-    for (auto &r : req) {
-        const size_t bytes = r.n * sizeof(float) + 256;
-        if (hipMalloc((void **)r.p, bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            for (auto &q : req) if (*q.p) { (void)hipFree(*q.p); *q.p = nullptr; }
-            fail(OFARN_E_NOMEM, "workspace of %zu bytes does not fit (max_batch=%d at %dx%d)", bytes, c->max_batch, c->max_w, c->max_h);
-            return 1;
-        }
-        c->ws_bytes += bytes;
-    }
+    if (ws_reserve(c, wi, 0, 0, F * (px * 5 + 4), 0, Pn * px * 2)) return 1;
     if (!c->aux[wi]) {
         if (hipStreamCreateWithFlags(&c->aux[wi], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_join[wi], hipEventDisableTiming) != hipSuccess) {
@@ -548,6 +583,20 @@ int alloc_workspace(ofarn_ctx *c, int wi)
         return 1;
     }
     return 0;
+}
+
+int begin_call(ofarn_ctx *c, hipStream_t s)
+{
+    if (c->have_last && c->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, c->ev_done, 0));
+    return OFARN_OK;
+}
+
+int end_call(ofarn_ctx *c, hipStream_t s)
+{
+    HIP_TRY(hipEventRecord(c->ev_done, s));
+    c->last_stream = s;
+    c->have_last = true;
+    return OFARN_OK;
 }
 
 }  // namespace ofarn_host
@@ -597,14 +646,13 @@ int ofarn_create(const ofarn_params *params, int device, int max_w, int max_h, i
     }
     auto bail = [&](int code) { ofarn_destroy(c); return code; };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess)
         return bail(fail(OFARN_E_HIP, "stream/event creation failed"));
     {
         const char *e = getenv("OFARN_SINGLE_STREAM");
         c->dual = !(e && e[0] == '1');
     }
-    const size_t px = (size_t)max_w * max_h;
-    c->tmp_floats = (size_t)2 * max_batch * px * 2;
     if (alloc_workspace(c, 0)) return bail(OFARN_E_NOMEM);
     if (params->flags & OFARN_FLAG_FARNEBACK_GAUSSIAN) {
         // FarnebackUpdateFlow_GaussianBlur: kernel[0] = 1, kernel[i] = (float)exp(-i*i/(2 sigma^2)), normalised
@@ -648,6 +696,7 @@ void ofarn_destroy(ofarn_ctx *c)
     for (int16_t *p : c->lk.der) if (p) (void)hipFree(p);
     for (auto &r : c->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : c->prof_free) (void)hipEventDestroy(e);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -766,6 +815,7 @@ int calc_batch_device_impl(ofarn_ctx *c, const uint8_t *d_frames, bool bgr, int 
     HIP_TRY(hipSetDevice(c->device));
     if ((rc = make_plan(c, w, h))) return rc;
     hipStream_t s = pick_stream(c, hip_stream);
+    if ((rc = begin_call(c, s))) return rc;
     const size_t fsz = (size_t)w * h;
     const int fstep = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? 1 : 2;
     const int nwaves = (n_pairs + c->max_batch - 1) / c->max_batch;
@@ -803,7 +853,7 @@ int calc_batch_device_impl(ofarn_ctx *c, const uint8_t *d_frames, bool bgr, int 
             HIP_TRY(hipEventRecord(c->ev_join[i], c->aux[i]));
             HIP_TRY(hipStreamWaitEvent(s, c->ev_join[i], 0));
         }
-    return OFARN_OK;
+    return end_call(c, s);
 }
 
 
@@ -849,6 +899,7 @@ int ofarn_calc_batch(ofarn_ctx *c, const uint8_t *h_frames, int n_frames, int w,
                              h_mask ? (size_t)wave * (c->P > 0 ? c->P : 1) : 0)))
         return rc;
     double ms_total = 0;
+    if ((rc = begin_call(c, c->stream))) return rc;
     for (int p0 = 0; p0 < n_pairs; p0 += wave) {
         const int np = n_pairs - p0 < wave ? n_pairs - p0 : wave;
         const int nf = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? np + 1 : 2 * np;
@@ -875,7 +926,7 @@ int ofarn_calc_batch(ofarn_ctx *c, const uint8_t *h_frames, int n_frames, int w,
         ms_total += ms;
     }
     c->last_ms = ms_total;
-    return OFARN_OK;
+    return end_call(c, c->stream);
 }
 
 int ofarn_calc(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next, int w, int h, int stride, float *h_flow)
@@ -888,6 +939,7 @@ int ofarn_calc(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next, int w
     if ((rc = make_plan(c, w, h))) return rc;
     const size_t fsz = (size_t)w * h;
     if ((rc = ensure_staging(c, 2 * fsz, fsz * 2 * sizeof(float), 0))) return rc;
+    if ((rc = begin_call(c, c->stream))) return rc;
     HIP_TRY(hipMemcpy2DAsync(c->st_frames, w, h_prev, stride, w, h, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpy2DAsync(c->st_frames + fsz, w, h_next, stride, w, h, hipMemcpyHostToDevice, c->stream));
     const bool use_init = (c->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW) != 0;
@@ -903,7 +955,7 @@ int ofarn_calc(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next, int w
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last_ms = ms;
-    return OFARN_OK;
+    return end_call(c, c->stream);
 }
 
 int ofarn_grid_filter_device(ofarn_ctx *c, const float *d_flow, int n, int w, int h, uint8_t *d_mask, uint8_t *d_v,
@@ -939,9 +991,11 @@ int ofarn_grid_filter(ofarn_ctx *c, const float *h_flow, int n, int w, int h, ui
     DevTmp iflow_tmp;
     if (h_iflow && (rc = iflow_tmp.alloc((size_t)c->P * 2 * sizeof(int32_t)))) return rc;
     int32_t *d_if = iflow_tmp.as<int32_t>();
+    if ((rc = begin_call(c, c->stream))) return rc;
     for (int i = 0; i < n; i++) {
         HIP_TRY(hipMemcpyAsync(c->st_flow, h_flow + (size_t)i * w * h * 2, fsz, hipMemcpyHostToDevice, c->stream));
         launch_grid_filter(c->stream, c->st_flow, w, h, 1, c->d_pts, c->P, c->prm.filter_variant, c->st_mask, c->st_v, d_if);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h_mask + (size_t)i * c->P, c->st_mask, c->P, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(h_v + (size_t)i * c->P, c->st_v, c->P, hipMemcpyDeviceToHost, c->stream));
         if (h_iflow)
@@ -949,7 +1003,7 @@ int ofarn_grid_filter(ofarn_ctx *c, const float *h_flow, int n, int w, int h, ui
                                    hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    return OFARN_OK;
+    return end_call(c, c->stream);
 }
 
 

@@ -221,6 +221,8 @@ int ofarn_stage_level_image(ofarn_ctx *c, const uint8_t *h_img, int w, int h, in
     const Level &L = c->lv[k];
     const size_t fsz = (size_t)w * h;
     if ((rc = ensure_staging(c, fsz, 0, 0))) return rc;
+    if ((rc = ws_reserve(c, 0, (size_t)h * L.w * 2, (size_t)L.w * L.h, 0, 0, 0))) return rc;
+    if ((rc = begin_call(c, c->stream))) return rc;
     HIP_TRY(hipMemcpyAsync(c->st_frames, h_img, fsz, hipMemcpyHostToDevice, c->stream));
     const bool lds_ok = (size_t)(w + 2 * (L.ksize / 2)) * 4 * 33 / 32 + 4 * (size_t)L.ksize + 64 <= 60 * 1024;
     if (!c->force_generic && level_direct_supported(c->st_frames, w, h, L.w, L.h, L.ksize))
@@ -236,7 +238,7 @@ int ofarn_stage_level_image(ofarn_ctx *c, const uint8_t *h_img, int w, int h, in
     }
     HIP_TRY(hipMemcpyAsync(h_out, c->ws[0].I, (size_t)L.w * L.h * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return OFARN_OK;
+    return end_call(c, c->stream);
 }
 
 // host <-> device layout helpers of the single-stage entry points (test-only paths)
@@ -263,6 +265,8 @@ int ofarn_stage_polyexp(ofarn_ctx *c, const float *h_img, int w, int h, float *h
     if (!h_img || !h_R) return fail(OFARN_E_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
     const size_t npx = (size_t)w * h;
+    if ((rc = ws_reserve(c, 0, 0, npx, 0, 0, 0))) return rc;
+    if ((rc = begin_call(c, c->stream))) return rc;
     HIP_TRY(hipMemcpyAsync(c->ws[0].I, h_img, npx * sizeof(float), hipMemcpyHostToDevice, c->stream));
     if (!c->force_generic && polyexp_march_supported(c->prm.poly_n)) {
         const float none[3] = {0, 0, 0};
@@ -273,7 +277,7 @@ int ofarn_stage_polyexp(ofarn_ctx *c, const float *h_img, int w, int h, float *h
     HIP_TRY(hipMemcpyAsync(dev.data(), c->ws[0].R, dev.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     r_from_device_layout(dev, npx, h_R);
-    return OFARN_OK;
+    return end_call(c, c->stream);
 }
 
 int ofarn_stage_update_matrices(ofarn_ctx *c, const float *h_R0, const float *h_R1, const float *h_flow, int w, int h,
@@ -287,6 +291,8 @@ int ofarn_stage_update_matrices(ofarn_ctx *c, const float *h_R0, const float *h_
     std::vector<float> d0, d1;
     r_to_device_layout(h_R0, npx, d0);
     r_to_device_layout(h_R1, npx, d1);
+    if ((rc = ws_reserve(c, 0, 0, 0, 0, npx * 5, 0))) return rc;
+    if ((rc = begin_call(c, c->stream))) return rc;
     HIP_TRY(hipMemcpyAsync(c->ws[0].R, d0.data(), d0.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->ws[0].R + r_frame_stride(npx), d1.data(), d1.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->ws[0].flowA, h_flow, npx * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -296,7 +302,7 @@ int ofarn_stage_update_matrices(ofarn_ctx *c, const float *h_R0, const float *h_
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (size_t o = 0; o < npx; o++)
         for (int ch = 0; ch < 5; ch++) h_M[o * 5 + ch] = mp[ch * npx + o];     // planar -> interleaved
-    return OFARN_OK;
+    return end_call(c, c->stream);
 }
 
 int ofarn_stage_blur_solve(ofarn_ctx *c, const float *h_M, int w, int h, float *h_flow)
@@ -309,6 +315,8 @@ int ofarn_stage_blur_solve(ofarn_ctx *c, const float *h_M, int w, int h, float *
     std::vector<float> mp(npx * 5);
     for (size_t o = 0; o < npx; o++)
         for (int ch = 0; ch < 5; ch++) mp[ch * npx + o] = h_M[o * 5 + ch];     // interleaved -> planar
+    if ((rc = ws_reserve(c, 0, 0, 0, 0, npx * 5, 0))) return rc;
+    if ((rc = begin_call(c, c->stream))) return rc;
     HIP_TRY(hipMemcpyAsync(c->ws[0].M, mp.data(), npx * 5 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     if (c->prm.flags & OFARN_FLAG_FARNEBACK_GAUSSIAN)
         launch_gauss_solve(c->stream, c->ws[0].M, c->ws[0].flowA, w, h, 1, c->prm.winsize, c->d_gwin);
@@ -316,7 +324,7 @@ int ofarn_stage_blur_solve(ofarn_ctx *c, const float *h_M, int w, int h, float *
         launch_blur_solve(c->stream, c->ws[0].M, c->ws[0].flowA, w, h, 1, c->prm.winsize);
     HIP_TRY(hipMemcpyAsync(h_flow, c->ws[0].flowA, npx * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return OFARN_OK;
+    return end_call(c, c->stream);
 }
 
 int ofarn_stage_flow_upsample(ofarn_ctx *c, const float *h_flow, int sw, int sh, int dw, int dh, float *h_out)
@@ -340,12 +348,13 @@ int ofarn_stage_flow_upsample(ofarn_ctx *c, const float *h_flow, int sw, int sh,
     HIP_TRY(hipMemcpy(d_xa, xa.data(), dw * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_yo, yo.data(), dh * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_ya, ya.data(), dh * sizeof(float), hipMemcpyHostToDevice));
+    if ((rc = begin_call(c, c->stream))) return rc;
     HIP_TRY(hipMemcpyAsync(c->ws[0].flowA, h_flow, (size_t)sw * sh * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     launch_flow_upsample(c->stream, c->ws[0].flowA, sw, sh, c->ws[0].flowB, dw, dh, 1, d_xo, d_xa, d_yo, d_ya,
                          (float)(1. / c->prm.pyr_scale));
     HIP_TRY(hipMemcpyAsync(h_out, c->ws[0].flowB, (size_t)dw * dh * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return OFARN_OK;
+    return end_call(c, c->stream);
 }
 
 #pragma GCC visibility pop

@@ -119,6 +119,7 @@ int ofarn_lk_calc_batch_device(ofarn_ctx *c, const uint8_t *d_frames, int n_fram
     if (n_pairs == 0 || npts == 0) return OFARN_OK;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = pick_stream(c, hip_stream);
+    if ((rc = begin_call(c, s))) return rc;                       // the LK pyramid workspace is shared between calls
     const size_t fsz = (size_t)w * h;
     const int fstep = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? 1 : 2;
     const int wave = c->max_batch < 64 ? c->max_batch : 64;      // LK keeps a small workspace of its own
@@ -133,7 +134,7 @@ int ofarn_lk_calc_batch_device(ofarn_ctx *c, const uint8_t *d_frames, int n_fram
                      d_next_pts + (size_t)p0 * npts * 2, d_status + (size_t)p0 * npts, d_err + (size_t)p0 * npts);
         if (rc) return rc;
     }
-    return OFARN_OK;
+    return end_call(c, s);
 }
 
 int ofarn_lk_calc(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next, int w, int h, int stride, const float *h_pts,
@@ -152,6 +153,7 @@ int ofarn_lk_calc(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next, in
     DevTmp pts, nxt, st, er;
     if ((rc = pts.alloc((size_t)npts * 8)) || (rc = nxt.alloc((size_t)npts * 8)) || (rc = st.alloc(npts)) || (rc = er.alloc((size_t)npts * 4)))
         return rc;
+    if ((rc = begin_call(c, c->stream))) return rc;
     HIP_TRY(hipMemcpy2DAsync(c->st_frames, w, h_prev, stride, w, h, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpy2DAsync(c->st_frames + fsz, w, h_next, stride, w, h, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(pts.p, h_pts, (size_t)npts * 8, hipMemcpyHostToDevice, c->stream));
@@ -164,7 +166,7 @@ int ofarn_lk_calc(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next, in
     HIP_TRY(hipMemcpyAsync(h_status, st.p, npts, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(h_err, er.p, (size_t)npts * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return OFARN_OK;
+    return end_call(c, c->stream);
 }
 
 int ofarn_vector_filter_device(ofarn_ctx *c, const float *d_vecs, int n, int w, int h, uint8_t *d_mask, uint8_t *d_v,
@@ -200,6 +202,7 @@ int ofarn_vector_filter(ofarn_ctx *c, const float *h_vecs, int n, int w, int h, 
     HIP_TRY(hipMemcpyAsync(vec.p, h_vecs, P * n * 8, hipMemcpyHostToDevice, c->stream));
     launch_grid_filter(c->stream, nullptr, w, h, n, c->d_pts, c->P, c->prm.filter_variant, mk.as<uint8_t>(), vv.as<uint8_t>(),
                        h_iflow ? ifl.as<int32_t>() : nullptr, vec.as<float>());
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_mask, mk.p, P * n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(h_v, vv.p, P * n, hipMemcpyDeviceToHost, c->stream));
     if (h_iflow) HIP_TRY(hipMemcpyAsync(h_iflow, ifl.p, P * n * 8, hipMemcpyDeviceToHost, c->stream));

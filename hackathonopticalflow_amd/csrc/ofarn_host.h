@@ -79,13 +79,23 @@ struct ofarn_ctx {
     // workspace
     // two workspaces: waves of one batch alternate between them on two internal streams, so the tail
     // of one wave's kernels overlaps the other wave's (the second is allocated on first use)
-    struct Workspace { float *tmp = nullptr, *I = nullptr, *R = nullptr, *M = nullptr, *flowA = nullptr, *flowB = nullptr; };
+    // R and the two flow buffers are sized for max_batch pairs when the context is created; tmp, I and M grow on
+    // demand to what the schedule of the call at hand needs (the fused default path needs no M and, at 1080p,
+    // 1.6 MB of tmp and 2 MB of I per frame instead of the 16.6 + 8.3 MB a full-resolution buffer would take).
+    struct Workspace {
+        float *tmp = nullptr, *I = nullptr, *R = nullptr, *M = nullptr, *flowA = nullptr, *flowB = nullptr;
+        size_t cap_tmp = 0, cap_I = 0, cap_R = 0, cap_M = 0, cap_flow = 0;   // capacities in floats
+    };
     Workspace ws[2];
+    // Ordering between calls on different streams: every entry point that enqueues work on the shared workspace
+    // records ev_done behind it; the next call waits for that event on ITS stream when the stream differs.
+    hipEvent_t ev_done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     bool dual = true;            // OFARN_SINGLE_STREAM=1 disables the second workspace
     uint64_t ws_bytes = 0;
-    size_t tmp_floats = 0;   // capacity of tmp in floats
     uint8_t *gray[2] = {nullptr, nullptr};   // gray frames of a wave when the caller hands over BGR (lazy)
     // sparse LK (lazy): pyramid levels >= 1 (uint8) and Scharr derivatives of every level (int16 x 2) for one wave of frames
     struct LkWs {
@@ -128,7 +138,13 @@ int make_plan(ofarn_ctx *c, int w, int h);
 int ensure_staging(ofarn_ctx *c, size_t frames_bytes, size_t flow_bytes, size_t dm_bytes);
 int build_area_tab(ofarn_ctx *c, int sw, int sh, int dw, int dh, ofarn::AreaTabHost &out);
 void resize_tables(int ssize, int dsize, std::vector<int> &ofs, std::vector<float> &alpha);
-hipEvent_t prof_event(ofarn_ctx *c);
+hipEvent_t prof_event(ofarn_ctx *c);   // nullptr if hipEventCreate fails (the launch then goes untimed)
+// Grow-only reservation of workspace `wi`, sizes in floats (0 = leave alone).  OFARN_E_NOMEM if it does not fit.
+int ws_reserve(ofarn_ctx *c, int wi, size_t tmp, size_t I, size_t R, size_t M, size_t flow);
+// Call ordering on the shared workspace (see ofarn_ctx::ev_done): begin_call before the first enqueue of an entry
+// point on stream s, end_call behind its last one.
+int begin_call(ofarn_ctx *c, hipStream_t s);
+int end_call(ofarn_ctx *c, hipStream_t s);
 
 // Runs `launch` and, when profiling is on, brackets it with two events on the same stream.
 template <typename F>
@@ -136,6 +152,12 @@ inline void timed(ofarn_ctx *c, hipStream_t s, int stage, int level, double unit
 {
     if (!c->prof_on) { launch(); return; }
     ofarn_ctx::ProfRec r{stage, level, units, prof_event(c), prof_event(c)};
+    if (!r.a || !r.b) {                       // no event to be had: run the launch untimed rather than record on a null handle
+        if (r.a) c->prof_free.push_back(r.a);
+        if (r.b) c->prof_free.push_back(r.b);
+        launch();
+        return;
+    }
     (void)hipEventRecord(r.a, s);
     launch();
     (void)hipEventRecord(r.b, s);

@@ -96,7 +96,6 @@ bool level_hdirect_supported(const void *frames, int W, int w, int ksize);
 void launch_level_hdirect(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
                           const float *h_kern, int ksize, float *tmp, int w);
 // Stage F: grid sample + vector filter + danger brightness.  d_pts int2[P] grid coordinates.
-int grid_filter_lds_bytes(int P);
 void launch_grid_filter(hipStream_t s, const float *flow, int w, int h, int npairs, const int *d_pts,
                         int P, int variant, uint8_t *mask, uint8_t *v, int32_t *iflow, const float *vecs = nullptr);
 

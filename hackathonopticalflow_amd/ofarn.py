@@ -15,9 +15,11 @@ There is no CPU fallback: if ``libofarn.so`` is missing or no GPU is visible, ca
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -263,6 +265,9 @@ def _ptr(t, name=None, dtype=None, min_elems=0):
     return C.c_void_p(t.data_ptr())
 
 
+_live_engines: "weakref.WeakSet" = weakref.WeakSet()   # every open context, closed at interpreter exit
+
+
 class FarnebackEngine:
     """One ofarn_ctx: a GPU, a parameter set, a maximum frame size and wave size.
 
@@ -275,6 +280,7 @@ class FarnebackEngine:
         h = C.c_void_p()
         _check(self._lib.ofarn_create(C.byref(self.params), device, max_width, max_height, max_batch, C.byref(h)))
         self._h = h
+        _live_engines.add(self)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -624,19 +630,51 @@ def _params_dict(p: OfarnParams):
 # ---------------------------------------------------------------------------------------------
 # Drop-in functions with the reference's names
 # ---------------------------------------------------------------------------------------------
-_engines: dict = {}
+_engines: dict = {}          # key -> _CachedEngine, oldest first
 _engines_lock = threading.Lock()
 
 
-def _engine_for(h, w, device, **params) -> FarnebackEngine:
+class _CachedEngine:
+    """A cached context plus the lock that serialises its users: an ofarn_ctx must not be used from two threads
+    at once, and eviction may only close it once nobody is inside a call."""
+    __slots__ = ("eng", "lock")
+
+    def __init__(self, eng):
+        self.eng = eng
+        self.lock = threading.Lock()
+
+
+class _EngineLease:
+    """``with _engine_for(...) as eng:`` -- holds the entry's lock for the duration of the call."""
+
+    def __init__(self, entry):
+        self._entry = entry
+
+    def __enter__(self) -> FarnebackEngine:
+        self._entry.lock.acquire()
+        if self._entry.eng is None:                       # evicted between lookup and use: rare, just fail loudly
+            self._entry.lock.release()
+            raise RuntimeError("cached engine was closed concurrently; retry the call")
+        return self._entry.eng
+
+    def __exit__(self, *a):
+        self._entry.lock.release()
+
+
+def _engine_for(h, w, device, **params) -> _EngineLease:
     key = (h, w, device, tuple(sorted(params.items())))
+    evicted = None
     with _engines_lock:
-        eng = _engines.get(key)
-        if eng is None:
+        entry = _engines.get(key)
+        if entry is None:
             if len(_engines) >= 8:   # bounded cache: drop the oldest context
-                _engines.pop(next(iter(_engines))).close()
-            eng = _engines[key] = FarnebackEngine(w, h, 1, device, **params)
-        return eng
+                evicted = _engines.pop(next(iter(_engines)))
+            entry = _engines[key] = _CachedEngine(FarnebackEngine(w, h, 1, device, **params))
+    if evicted is not None:
+        with evicted.lock:           # waits for a thread that is still inside a call on it
+            evicted.eng.close()
+            evicted.eng = None
+    return _EngineLease(entry)
 
 
 def calculate_optical_flow(prev, next, flow=None, pyr_scale=0.5, levels=3, winsize=15, iterations=3,
@@ -649,10 +687,10 @@ def calculate_optical_flow(prev, next, flow=None, pyr_scale=0.5, levels=3, winsi
     if prev_a.shape != next_a.shape:
         raise ValueError(f"prev and next must have the same size, got {prev_a.shape} and {next_a.shape}")
     h, w = prev_a.shape
-    eng = _engine_for(h, w, device, pyr_scale=float(pyr_scale), levels=int(levels), winsize=int(winsize),
-                      iterations=int(iterations), poly_n=int(poly_n), poly_sigma=float(poly_sigma),
-                      flags=int(flags))
-    return eng.calc(prev_a, next_a, flow)
+    with _engine_for(h, w, device, pyr_scale=float(pyr_scale), levels=int(levels), winsize=int(winsize),
+                     iterations=int(iterations), poly_n=int(poly_n), poly_sigma=float(poly_sigma),
+                     flags=int(flags)) as eng:
+        return eng.calc(prev_a, next_a, flow)
 
 
 def calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags):
@@ -666,10 +704,10 @@ def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 2
     """cv2.calcOpticalFlowPyrLK with cv2's names and defaults (pathfinder_viewer.py:156, DenseOF.py:183, SparseOF.py:35).
     Returns (nextPts, status, err): nextPts float32 shaped like prevPts, status uint8[n,1], err float32[n,1]."""
     a = _as_gray(prevImg, "prevImg")
-    eng = _engine_for(a.shape[0], a.shape[1], device)
     shape = np.shape(prevPts)
-    nxt, st, err = eng.lk(prevImg, nextImg, prevPts, nextPts, winSize=winSize, maxLevel=maxLevel, criteria=criteria,
-                          flags=flags, minEigThreshold=minEigThreshold)
+    with _engine_for(a.shape[0], a.shape[1], device) as eng:
+        nxt, st, err = eng.lk(prevImg, nextImg, prevPts, nextPts, winSize=winSize, maxLevel=maxLevel, criteria=criteria,
+                              flags=flags, minEigThreshold=minEigThreshold)
     return nxt.reshape(shape), st.reshape(-1, 1), err.reshape(-1, 1)
 
 
@@ -680,12 +718,13 @@ def get_flow_lk(img1, img2, points_, device=0):
     a = _as_gray(img1, "img1")
     h, w = a.shape
     pts = np.ascontiguousarray(np.asarray(points_, np.float32).reshape(-1, 2))
-    eng = _engine_for(h, w, device, grid_step=int(round(float(pts[1, 1] - pts[0, 1]))) if len(pts) > 1 and pts[1, 0] == pts[0, 0] else 30)
-    if not np.array_equal(pts, grid_points(w, h, eng.params.grid_step)):
+    step = int(round(float(pts[1, 1] - pts[0, 1]))) if len(pts) > 1 and pts[1, 0] == pts[0, 0] else 30
+    if not np.array_equal(pts, grid_points(w, h, step)):
         raise ValueError("points_ must be the measurement grid of pathfinder_viewer.py:255-267 for this frame size")
-    nxt, _st, _err = eng.lk(img2, img1, pts, None, winSize=(45, 45), maxLevel=2,
-                            criteria=(TERM_CRITERIA_EPS | TERM_CRITERIA_COUNT, 10, 0.03))
-    mask, _v, iflow = eng.vector_filter(nxt - pts, w, h, return_flow=True)
+    with _engine_for(h, w, device, grid_step=step) as eng:
+        nxt, _st, _err = eng.lk(img2, img1, pts, None, winSize=(45, 45), maxLevel=2,
+                                criteria=(TERM_CRITERIA_EPS | TERM_CRITERIA_COUNT, 10, 0.03))
+        mask, _v, iflow = eng.vector_filter(nxt - pts, w, h, return_flow=True)
     keep = mask.astype(bool)
     return None, iflow[keep], np.int32(pts + 0.5)[keep]
 
@@ -695,19 +734,22 @@ def cvtColor_bgr2gray(img, device=0):
     a = np.asarray(img)
     if a.ndim != 3:
         raise ValueError(f"img must be uint8[H,W,3], got shape {a.shape}")
-    return _engine_for(a.shape[0], a.shape[1], device).bgr2gray(a)
+    with _engine_for(a.shape[0], a.shape[1], device) as eng:
+        return eng.bgr2gray(a)
 
 
 def draw_hsv(flow_, device=0):
     """Drop-in for DenseOF.py:109-124 ``draw_hsv``: BGR uint8[H,W,3], hue = direction, value = 4 x length."""
     f = np.asarray(flow_)
-    return _engine_for(f.shape[0], f.shape[1], device).flow_hsv(f)
+    with _engine_for(f.shape[0], f.shape[1], device) as eng:
+        return eng.flow_hsv(f)
 
 
 def flow_lines(flow, step=14, device=0):
     """The `lines` array of DenseOF.py:40-49 ``draw_flow`` (int32[K,2,2]); cv2.polylines draws them."""
     f = np.asarray(flow)
-    return _engine_for(f.shape[0], f.shape[1], device).flow_arrows(f, step)
+    with _engine_for(f.shape[0], f.shape[1], device) as eng:
+        return eng.flow_arrows(f, step)
 
 
 def danger_map(flow, step=30, device=0, filter_variant=FILTER_VIEWER, return_flow=False):
@@ -715,12 +757,25 @@ def danger_map(flow, step=30, device=0, filter_variant=FILTER_VIEWER, return_flo
     filter_variant=FILTER_DENSEOF selects the older gate of DenseOF.py:228."""
     flow = np.asarray(flow)
     h, w = flow.shape[-3], flow.shape[-2]
-    eng = _engine_for(h, w, device, grid_step=int(step), filter_variant=int(filter_variant))
-    return eng.danger_map(flow, return_flow=return_flow)
+    with _engine_for(h, w, device, grid_step=int(step), filter_variant=int(filter_variant)) as eng:
+        return eng.danger_map(flow, return_flow=return_flow)
 
 
 def close_cached_engines():
+    """Closes every cached context.  Also registered with atexit, so that no ofarn_ctx outlives the HIP runtime
+    (ofarn_destroy after the runtime's own exit handlers have run would touch freed state)."""
     with _engines_lock:
-        for e in _engines.values():
-            e.close()
+        entries = list(_engines.values())
         _engines.clear()
+    for e in entries:
+        with e.lock:
+            if e.eng is not None:
+                e.eng.close()
+                e.eng = None
+
+
+@atexit.register
+def _close_all_engines():
+    close_cached_engines()
+    for eng in list(_live_engines):
+        eng.close()

@@ -7,8 +7,11 @@
  *   danger brightness V       pathfinder_viewer.py:204-217   (draw_sparse_lamps)
  * The NumPy lines themselves are re-typed in oracle/oracle.py (numpy IS importable here), so
  * this C twin is pinned against real NumPy float32/float64 semantics in tests/test_oracle_filter.py:
- * the mask is IEEE-only arithmetic (+,*,/,sqrt) and must match bit for bit; the integer flow
- * and V go through atan2f/cosf/sinf, whose last-ulp behaviour is library specific.
+ * the mask is IEEE-only arithmetic (+,*,/,sqrt) and must match bit for bit.  The integer flow and V go
+ * through arctan2 / cos / sin: NumPy's float32 loops for those are SIMD approximations (measured here: up to
+ * 3.2 ulp for arctan2, CPU dependent), so the contract the HIP kernels are held to is the CORRECTLY ROUNDED
+ * float32 value -- evaluated in double by the host libm and rounded once (OFO_CR_* below).  How often that
+ * differs from this container's NumPy after the integer truncation is measured in tests/test_oracle_filter.py.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  */
@@ -18,6 +21,11 @@
 #include <string.h>
 
 #define OFO_API __attribute__((visibility("default")))
+
+/* correctly rounded float32 arctan2 / cos / sin (double evaluation, one rounding) */
+static float ofo_cr_atan2f(float y, float x) { return (float)atan2((double)y, (double)x); }
+static float ofo_cr_cosf(float a) { return (float)cos((double)a); }
+static float ofo_cr_sinf(float a) { return (float)sin((double)a); }
 
 /* pathfinder_viewer.py:255-262: indent and np.mgrid[indent:size:step].astype(int) */
 static int ofo_axis_points(int size, int step, int *out)
@@ -96,23 +104,29 @@ OFO_API int ofo_vector_filter2(const float *vec, const float *pts, int P, int wi
     for (int i = 0; i < P; i++) {
         float fx = vec[i * 2], fy = vec[i * 2 + 1];
         float x = pts[i * 2], y = pts[i * 2 + 1];
-        float ang = atan2f(fy, fx);
+        float ang = ofo_cr_atan2f(fy, fx);
         float m = sqrtf(fx * fx + fy * fy);
         float ddx = (float)half_width - x, ddy = (float)half_height - y;
         float mm = sqrtf(ddx * ddx + ddy * ddy);
         m = m / (5.0f + sqrtf(mm)) * 30.0f;
         mod[i] = m;
         if (iflow) {
-            float gx = m * cosf(ang), gy = m * sinf(ang);
+            float gx = m * ofo_cr_cosf(ang), gy = m * ofo_cr_sinf(ang);
             int32_t nx = (int32_t)((x + gx) + 0.5f), ny = (int32_t)((y + gy) + 0.5f);
             int32_t px = (int32_t)(x + 0.5f), py = (int32_t)(y + 0.5f);
             iflow[i * 2] = nx - px; iflow[i * 2 + 1] = ny - py;
         }
     }
     memcpy(srt, mod, sizeof(float) * (size_t)P);
-    qsort(srt, (size_t)P, sizeof(float), cmp_f32);
-    float med = ofo_median_f32(srt, P) * 1.0f;
-    float p99 = ofo_percentile_f32(srt, P, 99.0f);
+    int has_nan = 0;
+    for (int i = 0; i < P; i++) if (mod[i] != mod[i]) has_nan = 1;
+    float med, p99;
+    if (has_nan) med = p99 = NAN;       /* np.median / np.percentile return NaN when the data hold one */
+    else {
+        qsort(srt, (size_t)P, sizeof(float), cmp_f32);
+        med = ofo_median_f32(srt, P) * 1.0f;
+        p99 = ofo_percentile_f32(srt, P, 99.0f);
+    }
     if (thr) { thr[0] = med; thr[1] = p99; }
     for (int i = 0; i < P; i++) {
         int keep = variant == 1 ? (mod[i] > med * 1.2f) : ((med < mod[i]) && (mod[i] < p99));

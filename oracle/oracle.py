@@ -330,9 +330,20 @@ def grid_points_numpy(width, height, step=30):
     return np.array(points).astype(np.float32).reshape(-1, 2)
 
 
-def vector_filter_numpy(flow_, points_, width, height, variant=0):
+def _cr(fn):
+    """Correctly rounded float32 version of a NumPy transcendental: evaluated in float64, rounded once.  NumPy's own
+    float32 arctan2 / cos / sin are SIMD approximations (up to 3.2 ulp for arctan2 on this container's build) that
+    differ between CPUs; the HIP kernels and the C oracle are held to the correctly rounded value instead."""
+    def f(*a):
+        return fn(*[np.asarray(x, np.float64) for x in a]).astype(np.float32)
+    return f
+
+
+def vector_filter_numpy(flow_, points_, width, height, variant=0, cr=True):
     """pathfinder_viewer.py:159-176, re-typed (flow_ = next_pts - points_ is the input here).
     variant=1 uses the older gate of DenseOF.py:228 instead of pathfinder_viewer.py:173.
+    cr=True evaluates arctan2 / cos / sin correctly rounded (see _cr); cr=False runs the lines literally,
+    i.e. with whatever this machine's NumPy float32 loops return.
 
     Returns mask bool[P], modulus float32[P], int flow int32[P,2] for ALL points
     (reference keeps [mask]), int points int32[P,2]."""
@@ -340,12 +351,13 @@ def vector_filter_numpy(flow_, points_, width, height, variant=0):
     half_height = int(height / 2)
     fx, fy = flow_[:, 0], flow_[:, 1]
     x, y = points_[:, 0], points_[:, 1]
-    ang = np.arctan2(fy, fx)
+    arctan2, cos, sin = (_cr(np.arctan2), _cr(np.cos), _cr(np.sin)) if cr else (np.arctan2, np.cos, np.sin)
+    ang = arctan2(fy, fx)
     modulus = np.sqrt(fx * fx + fy * fy)
     modulus_middle = np.sqrt((half_width - x) ** 2 + (half_height - y) ** 2)
     modulus = modulus / (5 + np.sqrt(modulus_middle)) * 30
-    fx = modulus * np.cos(ang)
-    fy = modulus * np.sin(ang)
+    fx = modulus * cos(ang)
+    fy = modulus * sin(ang)
     next_pts = np.vstack([x + fx, y + fy]).T
     next_pts = np.int32(next_pts + 0.5)
     ipoints = np.int32(points_ + 0.5)
@@ -366,7 +378,7 @@ def lamp_values_numpy(iflow_kept):
     return out
 
 
-def danger_map_numpy(flow_hw2, width, height, step=30, variant=0, return_flow=False):
+def danger_map_numpy(flow_hw2, width, height, step=30, variant=0, return_flow=False, cr=True):
     """Dense adaptation: sample flow[y,x] at the grid (DenseOF.py:44-45), then filter.
 
     Returns (mask u8[P], v u8[P]) with v = 0 at rejected points."""
@@ -374,7 +386,7 @@ def danger_map_numpy(flow_hw2, width, height, step=30, variant=0, return_flow=Fa
     xi = pts[:, 0].astype(np.int64)
     yi = pts[:, 1].astype(np.int64)
     vec = np.ascontiguousarray(flow_hw2[yi, xi, :], np.float32)
-    mask, _, iflow, _ = vector_filter_numpy(vec, pts, width, height, variant)
+    mask, _, iflow, _ = vector_filter_numpy(vec, pts, width, height, variant, cr=cr)
     v = np.zeros(len(pts), np.uint8)
     if mask.any():
         v[mask] = lamp_values_numpy(iflow[mask])
@@ -425,12 +437,12 @@ def hsv2bgr_u8(hsv):
     return out
 
 
-def draw_hsv_planes_numpy(flow_):
-    """DenseOF.py:109-120, re-typed: the uint8 HSV image draw_hsv hands to cv2.cvtColor."""
+def draw_hsv_planes_numpy(flow_, cr=True):
+    """DenseOF.py:109-120, re-typed: the uint8 HSV image draw_hsv hands to cv2.cvtColor.  cr: see vector_filter_numpy."""
     h, w = flow_.shape[:2]
     fx, fy = flow_[:, :, 0], flow_[:, :, 1]
 
-    ang = np.arctan2(fy, fx) + np.pi
+    ang = (_cr(np.arctan2) if cr else np.arctan2)(fy, fx) + np.pi
     v = np.sqrt(fx * fx + fy * fy)
 
     hsv = np.zeros((h, w, 3), np.uint8)
@@ -440,9 +452,9 @@ def draw_hsv_planes_numpy(flow_):
     return hsv
 
 
-def draw_hsv_numpy(flow_):
+def draw_hsv_numpy(flow_, cr=True):
     """draw_hsv (DenseOF.py:109-124): NumPy lines by the real NumPy, HSV2BGR by the C restatement."""
-    return hsv2bgr_u8(draw_hsv_planes_numpy(flow_))
+    return hsv2bgr_u8(draw_hsv_planes_numpy(flow_, cr=cr))
 
 
 def draw_flow_lines_numpy(img_shape, flow, step=14):

@@ -14,7 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from hackathonopticalflow_amd.synth import translated_pair  # noqa: E402
+from hackathonopticalflow_amd.synth import translated_pair, warped_pair  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 CASES = {
@@ -22,13 +22,19 @@ CASES = {
     "g160x120_L2": (120, 160, 501, dict(levels=2)),
     "g97x83_odd": (83, 97, 502, dict(levels=1, winsize=9, poly_n=7, poly_sigma=1.5)),
     "g192x144_scale08": (144, 192, 503, dict(levels=3, pyr_scale=0.8, iterations=2, winsize=8)),
+    # FPV-like family: zoom + rotation + sub-pixel shift + occluding patch (synth.warped_pair)
+    "g200x150_warp": (150, 200, 504, dict(levels=2)),
 }
 
 
 def main():
     out = os.path.dirname(os.path.abspath(__file__))
     for name, (h, w, seed, kw) in CASES.items():
-        prev, nxt, shift = translated_pair(h, w, seed, max_shift=4)
+        if name.endswith("_warp"):
+            prev, nxt, _, _ = warped_pair(h, w, seed)
+            shift = (0, 0)
+        else:
+            prev, nxt, shift = translated_pair(h, w, seed, max_shift=4)
         fd = O.farneback(prev, nxt, box_mode=O.BOX_BLOCKED, **kw)
         fr = O.farneback(prev, nxt, box_mode=O.BOX_RUNNING, **kw)
         mask, v = O.danger_map_numpy(fd, w, h, 30)

@@ -86,3 +86,24 @@ def test_gather_danger_maps_two_gloo_ranks(n_pairs):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` outside torch.distributed.run must spawn the two ranks itself (a fresh child through
+    torch.distributed.run, before anything touches HIP) and return the child's exit code.  Without a GPU the ranks stop
+    at "bench.py needs a GPU": seeing THAT message from a rank proves the launch path (the launcher stops the other rank
+    as soon as one has failed, so it may appear once or twice); with a GPU the same
+    command is tests/test_gpu_parity.py::test_bench_two_gloo_ranks_share_the_gpu."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: covered by the gpu-marked rehearsal")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "4",
+                        "--batch", "4", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert "bench.py needs a GPU" in r.stderr and "torch.distributed" in r.stderr, r.stderr[-2000:]
+    # a rank count that does not match the launch is refused
+    env2 = dict(env, RANK="0", WORLD_SIZE="3", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env2)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr
