@@ -917,7 +917,7 @@ def test_fine_grid_and_nan(H, oracle):
     rng = np.random.default_rng(5)
     w, h = 1920, 1080
     flow = (rng.standard_normal((h, w, 2)) * 3).astype(np.float32)
-    for step in (5, 7, 30, 200, 2000):
+    for step in (5, 7, 30, 200, 1000):
         mask, v = H.danger_map(flow, step)
         m_ref, v_ref = oracle.danger_map_numpy(flow, w, h, step)
         assert mask.shape == m_ref.shape
