@@ -125,16 +125,27 @@ __device__ __forceinline__ void gather_issue(const float *__restrict__ R0, const
     // in one 8-byte load (4-byte aligned: legal for global memory on gfx9+)
     {
         const char *b4 = reinterpret_cast<const char *>(R1);
+#ifdef OFARN_EXP_HALFTAPS   // experiment only (wrong results): what the kernel costs without the two right-hand tap loads
+        const float4 a00 = *reinterpret_cast<const float4 *>(b4 + q * 16u), a01 = a00;
+        const float4 a10 = *reinterpret_cast<const float4 *>(b4 + q10 * 16u), a11 = a10;
+        (void)q01; (void)q11;
+#else
         const float4 a00 = *reinterpret_cast<const float4 *>(b4 + q * 16u), a01 = *reinterpret_cast<const float4 *>(b4 + q01 * 16u);
         const float4 a10 = *reinterpret_cast<const float4 *>(b4 + q10 * 16u), a11 = *reinterpret_cast<const float4 *>(b4 + q11 * 16u);
+#endif
         g.t00[0] = a00.x; g.t00[1] = a00.y; g.t00[2] = a00.z; g.t00[3] = a00.w;
         g.t01[0] = a01.x; g.t01[1] = a01.y; g.t01[2] = a01.z; g.t01[3] = a01.w;
         g.t10[0] = a10.x; g.t10[1] = a10.y; g.t10[2] = a10.z; g.t10[3] = a10.w;
         g.t11[0] = a11.x; g.t11[1] = a11.y; g.t11[2] = a11.z; g.t11[3] = a11.w;
         struct __attribute__((packed, aligned(4))) F2 { float a, b; };
         const char *b1 = reinterpret_cast<const char *>(R1 + 4 * npx);
+#ifdef OFARN_EXP_HALFTAPS
+        const float s0a = *reinterpret_cast<const float *>(b1 + q * 4u), s1a = *reinterpret_cast<const float *>(b1 + q10 * 4u);
+        g.t00[4] = s0a; g.t01[4] = s0a; g.t10[4] = s1a; g.t11[4] = s1a;
+#else
         const F2 s0 = *reinterpret_cast<const F2 *>(b1 + q * 4u), s1 = *reinterpret_cast<const F2 *>(b1 + q10 * 4u);
         g.t00[4] = s0.a; g.t01[4] = s0.b; g.t10[4] = s1.a; g.t11[4] = s1.b;
+#endif
     }
 }
 

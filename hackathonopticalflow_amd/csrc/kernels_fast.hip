@@ -50,8 +50,9 @@ struct UpsampleArgs {
     int cw, ch;
     const int *xofs;
     const float *xa;
-    const int *yofs;
+    const int *yofs;        // (unused by the kernel: the row table is recomputed per row, see resize_coord)
     const float *ya;
+    double yscale;          // 1 / ((double)h / ch): resize.cpp's `scale` of the vertical axis
     float mul;
     unsigned long long *dbg;   // OFARN_STAMPS diagnostic build only: per-segment cycle sums
 };
@@ -117,6 +118,19 @@ __device__ __forceinline__ double wave_shl1(double edge, double src)
     return __hiloint2double(hi, lo);
 }
 
+// resize(INTER_LINEAR) source coordinate of destination index d (resize.cpp, the table the host builds in resize_tables()):
+// the same double and float operations in the same order, so the result equals the table entry bit for bit.  Used for the
+// ROW tables of the on-the-fly upsample: a table lookup per row is a scalar load whose latency sits in the row's critical
+// path (address -> four tap loads), the arithmetic is six VALU instructions on a uniform value.
+__device__ __forceinline__ void resize_coord(int d, double scale, int ssize, int &s, float &f)
+{
+    f = (float)(((double)d + 0.5) * scale - 0.5);
+    s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+}
+
 template <int M_, int MODE>   // MODE 0: flow_in == 0;  1: flow_in = upsample(coarse)*mul;  2: flow_in from HBM
 __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
                                                           const float2 *__restrict__ flow_in,
@@ -145,13 +159,12 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
 
     // per-thread constants of the on-the-fly upsample (resize INTER_LINEAR, horizontal weights)
     int usx = 0, usx1 = 0;
-    float ua0 = 0.f, ua1 = 0.f;
+    float ua1 = 0.f;
     const float2 *coarse = nullptr;
     if (MODE == 1) {
         usx = up.xofs[xc];
         usx1 = usx + 1 < up.cw ? usx + 1 : up.cw - 1;
         ua1 = up.xa[xc];
-        ua0 = 1.f - ua1;
         coarse = up.coarse + p * (size_t)up.cw * up.ch;
     }
 
@@ -159,21 +172,27 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
     // Row r of the matrices needs the flow at (xc, r), then a flow-dependent gather.  Both are long
     // latency, so they are issued one iteration (gather) and two iterations (flow) ahead of use and
     // land while the f64 box sums of the current row run.
+    // b1 (the row's vertical weight) is uniform: it lives in an SGPR, not in a VGPR of the 168-register budget
     struct FlowRaw { float2 p00, p01, p10, p11; float b1; };
     auto flow_issue = [&](int yy, FlowRaw &fr) {
         if (MODE == 2) fr.p00 = ldg_f2(fin, ((unsigned)yy * (unsigned)w + (unsigned)xc) * 8u);
         else if (MODE == 1) {
-            const int sy = up.yofs[yy];
+            int sy;
+            float b1;
+            resize_coord(yy, up.yscale, up.ch, sy, b1);
+            sy = __builtin_amdgcn_readfirstlane(sy);
+            fr.b1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b1)));
             const int sy1 = sy + 1 < up.ch ? sy + 1 : up.ch - 1;
-            fr.b1 = up.ya[yy];
-            fr.p00 = coarse[(size_t)sy * up.cw + usx]; fr.p01 = coarse[(size_t)sy * up.cw + usx1];
-            fr.p10 = coarse[(size_t)sy1 * up.cw + usx]; fr.p11 = coarse[(size_t)sy1 * up.cw + usx1];
+            const unsigned r0 = (unsigned)sy * (unsigned)up.cw, r1 = (unsigned)sy1 * (unsigned)up.cw;
+            fr.p00 = ldg_f2(coarse, (r0 + (unsigned)usx) * 8u); fr.p01 = ldg_f2(coarse, (r0 + (unsigned)usx1) * 8u);
+            fr.p10 = ldg_f2(coarse, (r1 + (unsigned)usx) * 8u); fr.p11 = ldg_f2(coarse, (r1 + (unsigned)usx1) * 8u);
         }
     };
     auto flow_finish = [&](const FlowRaw &fr, float &dx, float &dy) {
         dx = 0.f; dy = 0.f;
         if (MODE == 2) { dx = fr.p00.x; dy = fr.p00.y; }
         else if (MODE == 1) {
+            const float ua0 = 1.f - ua1;
             const float b1 = fr.b1, b0 = 1.f - b1;
             const float r0x = fr.p00.x * ua0 + fr.p01.x * ua1, r0y = fr.p00.y * ua0 + fr.p01.y * ua1;
             const float r1x = fr.p10.x * ua0 + fr.p11.x * ua1, r1y = fr.p10.y * ua0 + fr.p11.y * ua1;
@@ -903,7 +922,9 @@ static void launch_flow_iter_m(hipStream_t s, const float *R, int fstep, const f
     const int strip_h = B * best_strip_units(nblk, B, B - 1, (int)cdivu(w, OUTW) * npairs, 3);
     dim3 grid(cdivu(w, OUTW), cdivu(h, strip_h), npairs);
     const double scale = 1. / ((double)winsize * winsize);
-    UpsampleArgs up{reinterpret_cast<const float2 *>(coarse), cw, ch, d_xofs, d_xa, d_yofs, d_ya, mul, nullptr};
+    // resize_tables(): inv_scale = (double)dsize / ssize; scale = 1. / inv_scale
+    const double yscale = ch > 0 ? 1. / ((double)h / ch) : 1.;
+    UpsampleArgs up{reinterpret_cast<const float2 *>(coarse), cw, ch, d_xofs, d_xa, d_yofs, d_ya, yscale, mul, nullptr};
 #ifdef OFARN_STAMPS
     static unsigned long long *dbg = nullptr;
     static int calls = 0;

@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--w", type=int, default=1920)
     ap.add_argument("--h", type=int, default=1080)
     ap.add_argument("--no-danger", action="store_true")
+    ap.add_argument("--winsize", type=int, default=15)
+    ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--poly-n", type=int, default=5)
     a = ap.parse_args()
     import torch
     import hackathonopticalflow_amd as ofa
@@ -39,7 +42,8 @@ def main():
     P = len(ofa.grid_points(a.w, a.h, 30))
     mask = torch.zeros((a.batch, P), dtype=torch.uint8, device=dev)
     v = torch.zeros_like(mask)
-    eng = ofa.FarnebackEngine(a.w, a.h, a.batch, 0, levels=a.levels, iterations=a.iterations)
+    eng = ofa.FarnebackEngine(a.w, a.h, a.batch, 0, levels=a.levels, iterations=a.iterations, winsize=a.winsize, flags=a.flags,
+                              poly_n=a.poly_n, poly_sigma=1.2 if a.poly_n == 5 else 1.5)
     st = torch.cuda.current_stream().cuda_stream
     run = lambda: eng.calc_batch_device(frames, 2 * a.batch, a.w, a.h, ofa.PAIRS_INDEPENDENT, flow,
                                         None if a.no_danger else mask, None if a.no_danger else v, stream=st)
