@@ -1,0 +1,53 @@
+// flow_iter_common.h -- pieces shared by the fused iteration kernels (kernels_fast.hip: box window, kernels_gauss.hip:
+// Gaussian window): block geometry, the XCD-aware block remap, the on-the-fly upsample arguments.
+#pragma once
+#include "farneback_device.h"
+
+namespace ofarn {
+
+constexpr int FI_THREADS = 256;
+
+// XCD-aware block remap (speed only): the dispatcher deals consecutive workgroup ids round-robin over
+// the 8 XCDs, each with its own L2.  Regrouping ids so that ids congruent mod 8 become a contiguous
+// range puts neighbouring column strips -- which read each other's halo columns -- behind the same L2.
+__device__ __forceinline__ void xcd_remap(unsigned &bx, unsigned &by, unsigned &bz)
+{
+    const unsigned nx = gridDim.x, ny = gridDim.y, nb = nx * ny * gridDim.z;
+    unsigned lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    if ((nb & 7u) == 0) lin = (lin & 7u) * (nb >> 3) + (lin >> 3);
+    bx = lin % nx;
+    const unsigned q = lin / nx;
+    by = q % ny;
+    bz = q / ny;
+}
+
+struct UpsampleArgs {
+    const float2 *coarse;   // [P][ch][cw]
+    int cw, ch;
+    const int *xofs;
+    const float *xa;
+    const int *yofs;        // (unused by the kernel: the row table is recomputed per row, see resize_coord)
+    const float *ya;
+    double yscale;          // 1 / ((double)h / ch): resize.cpp's `scale` of the vertical axis
+    float mul;
+    unsigned long long *dbg;   // OFARN_STAMPS diagnostic build only: per-segment cycle sums
+};
+
+// resize(INTER_LINEAR) source coordinate of destination index d (resize.cpp, the table the host builds in resize_tables()):
+// the same double and float operations in the same order, so the result equals the table entry bit for bit.  Used for the
+// ROW tables of the on-the-fly upsample: a table lookup per row is a scalar load whose latency sits in the row's critical
+// path (address -> four tap loads), the arithmetic is six VALU instructions on a uniform value.
+__device__ __forceinline__ void resize_coord(int d, double scale, int ssize, int &s, float &f)
+{
+    f = (float)(((double)d + 0.5) * scale - 0.5);
+    s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+}
+
+
+// Strip height in `unit`-row steps for a marching kernel (kernels_fast.hip).
+int best_strip_units(int nunits, int unit, int warm, int blocks_per_strip_row, int blocks_per_cu);
+
+}  // namespace ofarn

@@ -22,40 +22,13 @@
 // (gathered, mostly sequential) and writes 8 B, x (256/(256-2m)) x ((strip_h+2m)/strip_h) halo
 // re-reads that L2 mostly absorbs; ~150 f64 adds per pixel keep the f64 pipe about half busy.
 #include "farneback_device.h"
+#include "flow_iter_common.h"
 #include "ofarn_internal.h"
 
 #include <cstdio>
 #include <type_traits>
 
 namespace ofarn {
-
-constexpr int FI_THREADS = 256;
-
-// XCD-aware block remap (speed only): the dispatcher deals consecutive workgroup ids round-robin over
-// the 8 XCDs, each with its own L2.  Regrouping ids so that ids congruent mod 8 become a contiguous
-// range puts neighbouring column strips -- which read each other's halo columns -- behind the same L2.
-__device__ __forceinline__ void xcd_remap(unsigned &bx, unsigned &by, unsigned &bz)
-{
-    const unsigned nx = gridDim.x, ny = gridDim.y, nb = nx * ny * gridDim.z;
-    unsigned lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
-    if ((nb & 7u) == 0) lin = (lin & 7u) * (nb >> 3) + (lin >> 3);
-    bx = lin % nx;
-    const unsigned q = lin / nx;
-    by = q % ny;
-    bz = q / ny;
-}
-
-struct UpsampleArgs {
-    const float2 *coarse;   // [P][ch][cw]
-    int cw, ch;
-    const int *xofs;
-    const float *xa;
-    const int *yofs;        // (unused by the kernel: the row table is recomputed per row, see resize_coord)
-    const float *ya;
-    double yscale;          // 1 / ((double)h / ch): resize.cpp's `scale` of the vertical axis
-    float mul;
-    unsigned long long *dbg;   // OFARN_STAMPS diagnostic build only: per-segment cycle sums
-};
 
 // Register FIFO with a UNIFORM runtime index: one 16- or 32-wide vector per channel, which the
 // backend keeps in VGPRs and addresses relative to M0 (v_movrels/v_movreld) -- no scratch memory, no
@@ -116,19 +89,6 @@ __device__ __forceinline__ double wave_shl1(double edge, double src)
     const int lo = __builtin_amdgcn_update_dpp((int)__double2loint(edge), (int)__double2loint(src), 0x130, 0xF, 0xF, false);
     const int hi = __builtin_amdgcn_update_dpp((int)__double2hiint(edge), (int)__double2hiint(src), 0x130, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
-}
-
-// resize(INTER_LINEAR) source coordinate of destination index d (resize.cpp, the table the host builds in resize_tables()):
-// the same double and float operations in the same order, so the result equals the table entry bit for bit.  Used for the
-// ROW tables of the on-the-fly upsample: a table lookup per row is a scalar load whose latency sits in the row's critical
-// path (address -> four tap loads), the arithmetic is six VALU instructions on a uniform value.
-__device__ __forceinline__ void resize_coord(int d, double scale, int ssize, int &s, float &f)
-{
-    f = (float)(((double)d + 0.5) * scale - 0.5);
-    s = (int)floorf(f);
-    f -= (float)s;
-    if (s < 0) { f = 0.f; s = 0; }
-    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
 }
 
 template <int M_, int MODE>   // MODE 0: flow_in == 0;  1: flow_in = upsample(coarse)*mul;  2: flow_in from HBM

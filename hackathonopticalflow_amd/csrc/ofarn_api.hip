@@ -337,7 +337,8 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
     float *prev = nullptr;
     int pw = 0, ph = 0;
     const bool gauss = (c->prm.flags & OFARN_FLAG_FARNEBACK_GAUSSIAN) != 0;
-    const bool fused = !c->force_generic && !gauss && c->prm.iterations >= 1 && flow_iter_supported(c->prm.winsize);
+    const bool fused = !c->force_generic && c->prm.iterations >= 1 &&
+                       (gauss ? flow_iter_gauss_supported(c->prm.winsize) : flow_iter_supported(c->prm.winsize));
     // Row pass of the level build for all levels that need one, in a single launch; tmp_of[k] is where level k's
     // rows go.  The plan is made first (offsets only), then the workspace is grown to what it needs.
     const bool march0 = !c->force_generic && polyexp_march_supported(c->prm.poly_n);
@@ -460,8 +461,12 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
                              : (busy == ws.flowA ? ws.flowB : ws.flowA);
                 const int mode = i == 0 ? (prev ? 1 : (cur ? 2 : 0)) : 2;
                 timed(c, s, OFARN_STAGE_FLOW_ITER, k, upx, [&] {
-                    launch_flow_iter(s, ws.R, fstep, cur, out, L.w, L.h, npairs, c->prm.winsize, mode, prev, pw, ph,
-                                     L.d_fxofs, L.d_fxa, L.d_fyofs, L.d_fya, mul);
+                    if (gauss)
+                        launch_flow_iter_gauss(s, ws.R, fstep, cur, out, L.w, L.h, npairs, c->prm.winsize, c->h_gwin.data(), mode,
+                                               prev, pw, ph, L.d_fxofs, L.d_fxa, L.d_fyofs, L.d_fya, mul);
+                    else
+                        launch_flow_iter(s, ws.R, fstep, cur, out, L.w, L.h, npairs, c->prm.winsize, mode, prev, pw, ph,
+                                         L.d_fxofs, L.d_fxa, L.d_fyofs, L.d_fya, mul);
                 });
                 cur = out;
             }
@@ -668,6 +673,7 @@ int ofarn_create(const ofarn_params *params, int device, int max_w, int max_h, i
         }
         sum = 1. / sum;
         for (int i = 0; i <= m; i++) k[i] = (float)(k[i] * sum);
+        c->h_gwin = k;
         if (hipMalloc((void **)&c->d_gwin, (m + 1) * sizeof(float)) != hipSuccess ||
             hipMemcpy(c->d_gwin, k.data(), (m + 1) * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(OFARN_E_HIP, "allocating the Gaussian window failed"));

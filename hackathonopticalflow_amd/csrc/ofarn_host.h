@@ -68,6 +68,7 @@ struct ofarn_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ofarn::PolyCoef poly{};
     float *d_gwin = nullptr;     // m+1 taps of the OPTFLOW_FARNEBACK_GAUSSIAN window
+    std::vector<float> h_gwin;   // host copy (passed by value to the fused Gaussian iteration kernel)
     // plan (cached for one frame size)
     int plan_w = 0, plan_h = 0;
     std::vector<ofarn_host::Level> lv;

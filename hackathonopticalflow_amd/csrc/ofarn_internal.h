@@ -63,6 +63,11 @@ bool flow_iter_supported(int winsize);
 void launch_flow_iter(hipStream_t s, const float *R, int fstep, const float *flow_in, float *flow_out, int w,
                       int h, int npairs, int winsize, int mode, const float *coarse, int cw, int ch,
                       const int *d_xofs, const float *d_xa, const int *d_yofs, const float *d_ya, float mul);
+// The same with the Gaussian window of OPTFLOW_FARNEBACK_GAUSSIAN (kernels_gauss.hip); h_kern: host pointer to the m+1 taps.
+bool flow_iter_gauss_supported(int winsize);
+void launch_flow_iter_gauss(hipStream_t s, const float *R, int fstep, const float *flow_in, float *flow_out, int w, int h,
+                            int npairs, int winsize, const float *h_kern, int mode, const float *coarse, int cw, int ch,
+                            const int *d_xofs, const float *d_xa, const int *d_yofs, const float *d_ya, float mul);
 // Stage B with compile-time radius, marching layout; with src_is_u8 the level-0 3-tap blur (stage A at
 // scale 1) is fused in and `src` are the uint8 frames.  blur3 = host pointer to the 3 kernel taps.
 bool polyexp_march_supported(int poly_n);

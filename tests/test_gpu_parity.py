@@ -236,9 +236,15 @@ def test_golden_fixtures(H, path):
 
 
 @pytest.mark.parametrize("w,h,kw", [(320, 240, dict(levels=2)), (333, 251, dict(levels=1, winsize=9, iterations=2)),
-                                    (200, 160, dict(levels=0, winsize=20))])
+                                    (200, 160, dict(levels=0, winsize=20)),
+                                    # the fused Gaussian iteration kernel: every instantiation (m = 3..8), multi-strip heights,
+                                    # one and several iterations (first iteration = on-the-fly upsample)
+                                    (521, 333, dict(levels=2, winsize=7)), (300, 420, dict(levels=2, winsize=11, iterations=2)),
+                                    (640, 480, dict(levels=3, winsize=13)), (300, 420, dict(levels=1, winsize=17, iterations=4)),
+                                    (1920, 1080, dict(levels=5)), (97, 83, dict(levels=1, winsize=19))])
 def test_farneback_gaussian_flag(H, oracle, w, h, kw):
-    """flags=OPTFLOW_FARNEBACK_GAUSSIAN (256): FarnebackUpdateFlow_GaussianBlur, float32 separable window."""
+    """flags=OPTFLOW_FARNEBACK_GAUSSIAN (256): FarnebackUpdateFlow_GaussianBlur, float32 separable window.  winsize 6..17
+    runs the fused marching kernel (kernels_gauss.hip), wider windows the unfused pair; both against the same oracle."""
     prev, nxt, _ = translated_pair(h, w, 51, max_shift=5)
     got = H.calculate_optical_flow(prev, nxt, flags=256, **kw)
     np.testing.assert_array_equal(got, oracle.farneback(prev, nxt, flags=256, **kw))
