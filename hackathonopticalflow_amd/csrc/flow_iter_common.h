@@ -7,6 +7,13 @@ namespace ofarn {
 
 constexpr int FI_THREADS = 256;
 
+// Output columns of a marching block with `halo` halo lanes per side: the largest multiple of 16 that the 256 threads
+// leave room for.  A block's row segment is then a whole number of 128-byte lines in every plane it writes (16 columns x
+// 8-byte flow, 8 columns x 16-byte R): with the natural width 256 - 2 * halo (242, 246) every block edge is a partially
+// written line that a neighbouring block on another CU completes at another time, and the marching stores of the
+// polynomial expansion reach 3.4 instead of 4.7 TB/s (tools/microbench/hbm_rw.hip).
+constexpr int march_out_width(int halo) { return (FI_THREADS - 2 * halo) & ~15; }
+
 // XCD-aware block remap (speed only): the dispatcher deals consecutive workgroup ids round-robin over
 // the 8 XCDs, each with its own L2.  Regrouping ids so that ids congruent mod 8 become a contiguous
 // range puts neighbouring column strips -- which read each other's halo columns -- behind the same L2.

@@ -98,7 +98,7 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
                                                           int strip_h, double scale, UpsampleArgs up)
 {
     constexpr int TAPS = 2 * M_ + 1;
-    constexpr int OUTW = FI_THREADS - 2 * M_;
+    constexpr int OUTW = march_out_width(M_);
     __shared__ double sV[2][5][FI_THREADS];
 
     const int tid = threadIdx.x;
@@ -210,7 +210,7 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
     __shared__ double sE[H3 ? 2 : 1][5][FI_THREADS / 64 + 1][2];   // first two column sums of every wave (edge buffer)
     double Vp[5] = {0, 0, 0, 0, 0};          // H3: this thread's column sums of the previous row
     const int tc = clampi(tid, M_, FI_THREADS - M_ - 1);   // halo threads redo a neighbour's sums (no branch)
-    const bool writer = tid >= M_ && tid < FI_THREADS - M_ && x < w;
+    const bool writer = tid >= M_ && tid < M_ + OUTW && x < w;
     auto hsum_row = [&](const int b, const int y) {
         double g[5];
         double chain = 0;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(FI_THREADS) void k_polyexp_march(const void *__rest
                                                               PolyCoef c, float k0, float k1, float k2)
 {
     constexpr int TAPS = 2 * N + 1;
-    constexpr int OUTW = FI_THREADS - 2 * N;
+    constexpr int OUTW = march_out_width(N);
     __shared__ float sRow[2][3][FI_THREADS];
 
     const int tid = threadIdx.x;
@@ -418,23 +418,38 @@ __global__ __launch_bounds__(FI_THREADS) void k_polyexp_march(const void *__rest
     const uint8_t *frm = SRC == 1 ? reinterpret_cast<const uint8_t *>(src) + (size_t)blockIdx.z * src_stride : nullptr;
     float *out = R + (size_t)blockIdx.z * r_frame_stride(npx);
 
-    // level-0 source: 3-tap blur state for this column (row pass of rows yy-1, yy, yy+1)
+    // Source of the level-image value of one row of this column, split in two so that the loads of row y+1 are ISSUED
+    // before the stores of row y and their data is first touched in the next turn of the loop: vmcnt counts loads and
+    // stores together and retires them in order, so a load issued behind a row's stores cannot be waited for without
+    // waiting for those stores too -- every row then pays the full write latency.
+    //   SRC 0: the float level image.  SRC 1: level 0, 3-tap blur state (row pass of rows yy-1, yy, yy+1) from the bytes.
     const int xl = reflect101(xc - 1, w), xr = reflect101(xc + 1, w);
-    float rpm = 0.f, rpc = 0.f, rpp = 0.f, icur = 0.f;
+    float rpm = 0.f, rpc = 0.f, rpp = 0.f, icur = 0.f, pf = 0.f;
+    uint8_t nl = 0, nc = 0, nr = 0;
     int ry = -0x40000000;
-    auto rowpass = [&](int row) {
-        const uint8_t *f = frm + (size_t)row * w;
-        float s = k0 * (float)f[xl];
-        s = s + k1 * (float)f[xc];
-        s = s + k2 * (float)f[xr];
+    auto rowpass3 = [&](uint8_t a, uint8_t b, uint8_t cc) {
+        float s = k0 * (float)a;
+        s = s + k1 * (float)b;
+        s = s + k2 * (float)cc;
         return s;
     };
-    auto level_at = [&](int yy) -> float {   // yy in [0, h-1], non-decreasing from call to call
-        if (SRC == 0) return img[(size_t)yy * w + xc];
+    auto rowpass = [&](int row) {
+        const uint8_t *f = frm + (size_t)row * w;
+        return rowpass3(f[xl], f[xc], f[xr]);
+    };
+    // issue_next(yy): loads for the value finish(yy) will return (yy in [0, h-1], non-decreasing from call to call)
+    auto issue_next = [&](int yy) {
+        if (SRC == 0) pf = img[(size_t)yy * w + xc];
+        else if (yy == ry + 1) {                         // uniform; the other cases need no new row or take the slow path
+            const uint8_t *f = frm + (size_t)reflect101(yy + 1, h) * w;
+            nl = f[xl]; nc = f[xc]; nr = f[xr];
+        }
+    };
+    auto finish = [&](int yy) -> float {
+        if (SRC == 0) return pf;
         if (yy == ry) return icur;
-        if (yy == ry + 1) { rpm = rpc; rpc = rpp; }
-        else { rpm = rowpass(reflect101(yy - 1, h)); rpc = rowpass(yy); }
-        rpp = rowpass(reflect101(yy + 1, h));
+        if (yy == ry + 1) { rpm = rpc; rpc = rpp; rpp = rowpass3(nl, nc, nr); }
+        else { rpm = rowpass(reflect101(yy - 1, h)); rpc = rowpass(yy); rpp = rowpass(reflect101(yy + 1, h)); }
         ry = yy;
         icur = k1 * rpc + k2 * (rpp + rpm);
         return icur;
@@ -442,14 +457,24 @@ __global__ __launch_bounds__(FI_THREADS) void k_polyexp_march(const void *__rest
 
     float win[TAPS];
     for (int j = 1; j < TAPS; j++) {
-        const float v = level_at(clampi(y0 - N + (j - 1), 0, h - 1));
+        const int yy = clampi(y0 - N + (j - 1), 0, h - 1);
+        issue_next(yy);
+        const float v = finish(yy);
 #pragma unroll
         for (int q = 1; q < TAPS; q++) if (q == j) win[q] = v;
     }
 
     int buf = 0;
+    const bool writer = tid >= N && tid < N + OUTW && x < w;
+    float pv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};     // the previous row's result, stored one turn late (see below)
+    issue_next(clampi(y0 + N, 0, h - 1));
     for (int y = y0; y < y1; y++) {
-        const float v = level_at(clampi(y + N, 0, h - 1));
+        const float v = finish(clampi(y + N, 0, h - 1));
+        issue_next(clampi(y + 1 + N, 0, h - 1));
+        // The stores of row y-1 go out HERE, behind the loads of row y+1 and a whole row of arithmetic before the next
+        // wait on a load: the compiler's wait for those loads is a plain vmcnt(0), which also waits for every store issued
+        // before it -- stores issued at the end of a row would be waited for at once, with their full write latency exposed.
+        if (y > y0 && writer) store_r(out, npx, (unsigned)(y - 1) * (unsigned)w + (unsigned)x, pv);
 #pragma unroll
         for (int j = 0; j < TAPS - 1; j++) win[j] = win[j + 1];
         win[TAPS - 1] = v;
@@ -465,8 +490,8 @@ __global__ __launch_bounds__(FI_THREADS) void k_polyexp_march(const void *__rest
         sRow[buf][0][tid] = r0;
         sRow[buf][1][tid] = r1;
         sRow[buf][2][tid] = r2;
-        barrier_lds_only();   // __syncthreads() would also drain vmcnt (the previous row's stores)
-        if (tid >= N && tid < FI_THREADS - N && x < w) {
+        barrier_lds_only();   // __syncthreads() would also drain vmcnt
+        if (writer) {
             const float *p0 = &sRow[buf][0][tid], *p1 = &sRow[buf][1][tid], *p2 = &sRow[buf][2][tid];
             const float g0 = c.g[0];
             double b1 = p0[0] * g0, b2 = 0, b3 = p1[0] * g0, b4 = 0, b5 = p2[0] * g0, b6 = 0;
@@ -483,12 +508,15 @@ __global__ __launch_bounds__(FI_THREADS) void k_polyexp_march(const void *__rest
                 b6 += (p1[k] - p1[-k]) * xgk;
                 b5 += (p2[k] + p2[-k]) * gk;
             }
-            const float rv[5] = {(float)(b3 * c.ig11), (float)(b2 * c.ig11), (float)(b1 * c.ig03 + b5 * c.ig33),
-                                 (float)(b1 * c.ig03 + b4 * c.ig33), (float)(b6 * c.ig55)};
-            store_r(out, npx, (unsigned)y * (unsigned)w + (unsigned)x, rv);
+            pv[0] = (float)(b3 * c.ig11);
+            pv[1] = (float)(b2 * c.ig11);
+            pv[2] = (float)(b1 * c.ig03 + b5 * c.ig33);
+            pv[3] = (float)(b1 * c.ig03 + b4 * c.ig33);
+            pv[4] = (float)(b6 * c.ig55);
         }
         buf ^= 1;
     }
+    if (y1 > y0 && writer) store_r(out, npx, (unsigned)(y1 - 1) * (unsigned)w + (unsigned)x, pv);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -874,7 +902,7 @@ static void launch_flow_iter_m(hipStream_t s, const float *R, int fstep, const f
                                int h, int npairs, int winsize, int mode, const float *coarse, int cw, int ch,
                                const int *d_xofs, const float *d_xa, const int *d_yofs, const float *d_ya, float mul)
 {
-    constexpr int OUTW = FI_THREADS - 2 * M_;
+    constexpr int OUTW = march_out_width(M_);
     constexpr int B = 2 * M_ + 1;
     // strips start on block boundaries of the blocked column sums (multiples of B rows); their
     // number is chosen to minimise (rounds of resident blocks) x (rows marched per block)
@@ -968,7 +996,7 @@ template <int N>
 static void launch_polyexp_march_n(hipStream_t s, const void *src, size_t src_stride, int src_is_u8, float *R, int w, int h,
                                    int nframes, const PolyCoef &c, const float *blur3)
 {
-    constexpr int OUTW = FI_THREADS - 2 * N;
+    constexpr int OUTW = march_out_width(N);
     const int strip_h = best_strip_units(h, 1, 2 * N, (int)cdivu(w, OUTW) * nframes, 6);
     dim3 grid(cdivu(w, OUTW), cdivu(h, strip_h), nframes);
     if (src_is_u8)

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(FI_THREADS, OFARN_GAUSS_WAVES) void k_flow_iter_gau
                                                                                    int strip_h, GaussTaps<M_> taps, UpsampleArgs up)
 {
     constexpr int TAPS = 2 * M_ + 1;
-    constexpr int OUTW = FI_THREADS - 2 * M_;
+    constexpr int OUTW = march_out_width(M_);
     __shared__ float sV[2][5][FI_THREADS];
 
     const int tid = threadIdx.x;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(FI_THREADS, OFARN_GAUSS_WAVES) void k_flow_iter_gau
 
     const int nsteps = (y1 - y0) + TAPS - 1;   // padded rows y0 .. y1+2m-1; step s emits output row y0 + s - 2m
     const int tc = clampi(tid, M_, FI_THREADS - M_ - 1);   // halo threads redo a neighbour's row pass (no branch)
-    const bool writer = tid >= M_ && tid < FI_THREADS - M_ && x < w;
+    const bool writer = tid >= M_ && tid < M_ + OUTW && x < w;
 
     // row pass + solve of the row whose column sums are in sV[b]
     auto hsum_row = [&](const int b, const int y) {
@@ -223,7 +223,7 @@ static void launch_flow_iter_gauss_mm(hipStream_t s, const float *R, int fstep, 
                                       int h, int npairs, const float *h_kern, const float *coarse, int cw, int ch,
                                       const int *d_xofs, const float *d_xa, const int *d_yofs, const float *d_ya, float mul)
 {
-    constexpr int OUTW = FI_THREADS - 2 * M_;
+    constexpr int OUTW = march_out_width(M_);
     constexpr int B = 2 * M_ + 1;
     GaussTaps<M_> taps;
     for (int i = 0; i <= M_; i++) taps.k[i] = h_kern[i];
