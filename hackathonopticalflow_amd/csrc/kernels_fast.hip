@@ -764,7 +764,9 @@ __global__ __launch_bounds__(EDGE ? 64 : 256) void k_level_direct(const uint8_t 
 // level column): the K+1 source bytes of its two sampled columns start at S*x + S/2 - 1 - K/2, which is a multiple
 // of 4 for these (S, K), so they arrive as (K+1)/4 aligned dwords and are unpacked with v_cvt_f32_ubyteN; taps are
 // kernel arguments (SGPRs).  Same arithmetic and order as k_level_hpass*.  EDGE: columns 0 and w-1, whose taps
-// cross the frame border, with reflected byte loads in a second tiny launch.
+// cross the frame border, in a second small launch -- blockIdx.x picks the side, so the reflect-101 source index of every
+// tap is a compile-time offset from the start (left) or the end (right) of the row: the bytes arrive as aligned dwords
+// all issued at once, like the interior's (80 dependent byte loads per thread made this launch slower than the interior's).
 // ---------------------------------------------------------------------------------------------
 constexpr int HD_ROWS = 4;
 
@@ -776,9 +778,8 @@ __global__ __launch_bounds__(EDGE ? 64 : 128) void k_level_hdirect(const uint8_t
     static_assert((S / 2 - 1 - r) % 4 == 0 && (K + 1) % 4 == 0, "window must start on a dword and span whole dwords");
     int x, y;
     if (EDGE) {
-        x = (threadIdx.x & 1) ? w - 1 : 0;
-        y = blockIdx.y * 32 + (threadIdx.x >> 1);
-        if (w == 1 && (threadIdx.x & 1)) return;
+        x = blockIdx.x ? w - 1 : 0;
+        y = blockIdx.y * 64 + threadIdx.x;
     } else {
         x = 1 + blockIdx.x * blockDim.x + threadIdx.x;
         y = blockIdx.y * HD_ROWS;
@@ -791,13 +792,40 @@ __global__ __launch_bounds__(EDGE ? 64 : 128) void k_level_hdirect(const uint8_t
     const uint8_t *row = frames + (size_t)blockIdx.z * frame_stride + (size_t)y * W;
     float a0 = 0.f, a1 = 0.f;
     if (EDGE) {
-        float prev = (float)row[reflect101_once(cl, W)];
-        a0 = taps.k[0] * prev;
-#pragma unroll 8
-        for (int t = 1; t <= K; t++) {
-            const float v = (float)row[reflect101_once(cl + t, W)];
-            if (t < K) a0 = a0 + taps.k[t] * v;
-            a1 = t == 1 ? taps.k[0] * v : a1 + taps.k[t - 1] * v;
+        // left:  tap t reads column |c0 + t| with c0 = S/2-1-r < 0            -> bytes 0 .. c0+K of the row
+        // right: tap t reads column W + p, p = cR + t, cR = -S/2-1-r, reflected to W - 2 - p where p >= 0
+        //                                                                     -> bytes W+cR .. W-1 of the row
+        constexpr int c0 = S / 2 - 1 - r, cR = -S / 2 - 1 - r;
+        static_assert(c0 < 0 && (-cR) % 4 == 0 && c0 + K < 2 * S && cR + K < -cR, "edge windows must fold once, inside 2*S columns");
+        constexpr int NDL = (c0 + K) / 4 + 1, NDR = -cR / 4;
+        uint32_t d[NDL > NDR ? NDL : NDR];
+        float px[K + 1];
+        if (blockIdx.x == 0) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(row);
+#pragma unroll
+            for (int i = 0; i < NDL; i++) d[i] = q[i];
+#pragma unroll
+            for (int t = 0; t <= K; t++) {
+                const int idx = c0 + t < 0 ? -(c0 + t) : c0 + t;
+                px[t] = (float)((d[idx / 4] >> (8 * (idx % 4))) & 255u);
+            }
+        } else {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(row + (W + cR));
+#pragma unroll
+            for (int i = 0; i < NDR; i++) d[i] = q[i];
+#pragma unroll
+            for (int t = 0; t <= K; t++) {
+                const int p = cR + t;
+                const int idx = (p >= 0 ? -2 - p : p) - cR;
+                px[t] = (float)((d[idx / 4] >> (8 * (idx % 4))) & 255u);
+            }
+        }
+        a0 = taps.k[0] * px[0];
+        a1 = taps.k[0] * px[1];
+#pragma unroll
+        for (int t = 1; t < K; t++) {
+            a0 = a0 + taps.k[t] * px[t];
+            a1 = a1 + taps.k[t] * px[t + 1];
         }
     } else {
         const uint32_t *q = reinterpret_cast<const uint32_t *>(row + cl);
@@ -835,7 +863,7 @@ static void launch_level_hdirect_sk(hipStream_t s, const uint8_t *frames, size_t
         dim3 grid((unsigned)((w - 2 + nt - 1) / nt), (unsigned)((H + HD_ROWS - 1) / HD_ROWS), nframes);
         hipLaunchKernelGGL((k_level_hdirect<S, K, false>), grid, dim3(nt), 0, s, frames, frame_stride, W, H, taps, t2, w);
     }
-    dim3 egrid(1, (unsigned)((H + 31) / 32), nframes);
+    dim3 egrid(2, (unsigned)((H + 63) / 64), nframes);     // x: left / right border column (w >= 2 here)
     hipLaunchKernelGGL((k_level_hdirect<S, K, true>), egrid, dim3(64), 0, s, frames, frame_stride, W, H, taps, t2, w);
 }
 
