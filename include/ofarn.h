@@ -19,6 +19,14 @@
  *
  * Pointer naming: h_* = host memory, d_* = device (HBM) memory of the context's GPU.
  * A context is bound to one GPU and must not be used from two threads at once.
+ *
+ * Streams and ordering.  Device entry points (*_device) enqueue on the caller's `hip_stream` and return without
+ * synchronising; host entry points run on the context's own stream and return when their result is in host memory.
+ * All entry points of one context share its workspace, so the context orders its calls itself: every call records an
+ * event behind its last kernel, and the next call -- whatever stream it is given -- first makes that stream wait for
+ * the event.  Calls issued from one thread therefore behave as if the context had a single queue; work the CALLER has
+ * queued on other streams (producing the input frames, consuming the flow) is the caller's to order, as with any
+ * stream-based library.
  */
 #ifndef OFARN_H
 #define OFARN_H
@@ -39,7 +47,7 @@ extern "C" {
 /* flags (cv2 names OPTFLOW_*).  With USE_INITIAL_FLOW the flow buffer of every calc entry point is an
  * in/out argument, as cv2's `flow` is: on entry it holds the full-resolution initial flow of each pair. */
 #define OFARN_FLAG_USE_INITIAL_FLOW 4
-#define OFARN_FLAG_FARNEBACK_GAUSSIAN 256
+#define OFARN_FLAG_FARNEBACK_GAUSSIAN 256   /* winsize 6..17: fused marching kernel; wider windows: one kernel per stage */
 
 /* pairs_mode of the batch entry points */
 #define OFARN_PAIRS_INDEPENDENT 0 /* frames (2i, 2i+1) form pair i; n_pairs = n_frames/2          */
@@ -207,7 +215,9 @@ int ofarn_profile_enable(ofarn_ctx *ctx, int on);
 int ofarn_profile_read(ofarn_ctx *ctx, int cap, int *stage, int *level, int *launches, double *ms,
                        double *units);
 
-/* Bytes of HBM workspace held by the context. */
+/* Bytes of HBM workspace held by the context right now.  The polynomial-expansion and flow buffers are sized for
+ * max_batch pairs by ofarn_create; level-image, row-pass and (unfused paths only) matrix buffers are allocated by the
+ * first call that needs them, so the figure grows until the first batch has run (123 MB per 1080p pair by default). */
 uint64_t ofarn_workspace_bytes(const ofarn_ctx *ctx);
 
 /* Library build string: "ofarn <version> gfx950 ...". */

@@ -131,6 +131,17 @@ with open(f"{P}/{tag}_pmc_derived.txt", "w") as o:
             if g(c) is not None:
                 o.write(f"    {c:52s} {g(c):16.1f}\n")
         o.write("\n")
+# whole pipeline: HBM bytes of every ofarn kernel of the one-wave pass (256 pairs), reads doubled as above
+tot_f = tot_w = 0.0
+for k, cs in cnt.items():
+    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        tot_f += sum(cs["FETCH_SIZE"]) * 1024      # kbench --reps 1: one profiled pass (+ one warm-up pass, same kernels)
+        tot_w += sum(cs["WRITE_SIZE"]) * 1024
+if tot_f:
+    passes = 2      # kbench runs the pass once untimed and once timed; both are in the counter file
+    traffic["pipeline_hbm_bytes_per_pair"] = round((2 * tot_f + tot_w) / passes / 256)
+    traffic["pipeline_hbm_bytes_note"] = ("sum over all kernels of one pass of 256 pairs of (2 x FETCH_SIZE + WRITE_SIZE) / 256; "
+                                          "algorithmic (SURVEY 8(d)): 1003.4 MB per pair")
 if len(traffic) > 1:
     old = {}
     try:
