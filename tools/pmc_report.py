@@ -48,8 +48,9 @@ if trace:
             int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     with open(f"{P}/{tag}_kernel_stats_by_grid.csv", "w") as o:
         o.write("# Derived from the kernel trace of the same rocprofv3 --kernel-trace --stats run as the _kernel_stats.csv next to it:\n"
-                "# split per kernel, grid (= pyramid level) and stream.  The profiled steps run on the caller's stream (per-kernel timing on);\n"
-                "# the warm-up step runs on the two internal streams, where kernels of two waves overlap and each one's duration is about doubled.\n")
+                "# split per kernel, grid (= pyramid level; grid_z = frames or pairs of the wave) and stream.  bench.py's line of the same run is\n"
+                "# profiles/<tag>_trace_bench.json: its roofline.kernel_avg_ms (HIP events) is the mean of the level-0 k_flow_iter rows here.\n"
+                "# Rows on other streams than the first belong to the informational two-stream leg (two half-size waves overlapping).\n")
         o.write("kernel,grid_x,grid_y,grid_z,stream_id,vgpr,scratch,lds,calls,avg_ns,total_ns\n")
         for k in sorted(acc, key=lambda k: -sum(acc[k])):
             v = acc[k]
