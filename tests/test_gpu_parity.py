@@ -994,3 +994,31 @@ def test_bench_two_gloo_ranks_share_the_gpu():
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["global_pairs"] == 16
     assert out["config"]["pairs_per_gpu"] == 8 and out["value"] > 0
     assert out["gathered_danger_maps_checked"] is True
+
+
+def test_workspace_grows_on_demand_and_fails_cleanly(H, oracle, monkeypatch):
+    """R and the flow buffers are reserved by ofarn_create, the level-image / row-pass / matrix buffers by the first call that
+    needs them (round 1 reserved all of them at full resolution: 207 MB per 1080p pair, now 123).  A context that cannot get
+    its memory fails with MemoryError (OFARN_E_NOMEM), not with a crash."""
+    a, b, _ = translated_pair(240, 320, 61, max_shift=3)
+    c, d, _ = translated_pair(480, 640, 62, max_shift=3)
+    with H.FarnebackEngine(640, 480, 2, levels=3) as eng:
+        w0 = eng.workspace_bytes
+        assert w0 >= 2 * 2 * (640 * 480 * 5 + 4) * 4 + 2 * 2 * 640 * 480 * 2 * 4      # R for 4 frames + two flow buffers for 2 pairs
+        assert w0 < 2 * 207e6 * (640 * 480) / (1920 * 1080)                           # nothing else yet
+        np.testing.assert_array_equal(eng.calc(a, b), oracle.farneback(a, b, levels=3, box_mode=oracle.BOX_BLOCKED))
+        w1 = eng.workspace_bytes
+        np.testing.assert_array_equal(eng.calc(c, d), oracle.farneback(c, d, levels=3, box_mode=oracle.BOX_BLOCKED))
+        w2 = eng.workspace_bytes
+        np.testing.assert_array_equal(eng.calc(a, b), oracle.farneback(a, b, levels=3, box_mode=oracle.BOX_BLOCKED))
+        assert w0 < w1 < w2 == eng.workspace_bytes                                    # grows with the shapes seen, never shrinks
+        M = np.random.default_rng(0).standard_normal((480, 640, 5)).astype(np.float32)
+        eng.stage_blur_solve(M)                                                       # the unfused stage needs M: allocated now
+        assert eng.workspace_bytes > w2
+    # the unfused path (OFARN_FORCE_GENERIC) allocates M for the batch and still matches
+    monkeypatch.setenv("OFARN_FORCE_GENERIC", "1")
+    with H.FarnebackEngine(640, 480, 1, levels=3) as eng:
+        np.testing.assert_array_equal(eng.calc(c, d), oracle.farneback(c, d, levels=3, box_mode=oracle.BOX_BLOCKED))
+    monkeypatch.delenv("OFARN_FORCE_GENERIC")
+    with pytest.raises(MemoryError):
+        H.FarnebackEngine(3840, 2160, 4000)          # 4000 pairs of 4K: ~2 TB of R alone
