@@ -8,7 +8,7 @@ import sys, os
 sys.path.insert(0, '.')
 import numpy as np
 import hackathonopticalflow_amd as H
-from hackathonopticalflow_amd.synth import translated_pair
+from hackathonopticalflow_amd.synth import translated_pair, warped_pair
 from oracle import oracle as O
 O.build()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 123)
@@ -21,7 +21,12 @@ for i in range(N):
               poly_n=int(rng.choice([3, 5, 5, 5, 7, 7])), poly_sigma=float(rng.choice([1.1, 1.2, 1.5])),
               pyr_scale=float(rng.choice([0.5, 0.5, 0.5, 0.6, 0.75, 0.8])), flags=int(rng.choice([0, 0, 0, 4, 256, 260])))
     os.environ["OFARN_DIRECT_MIN_FRAMES"] = str(int(rng.choice([1, 32])))
-    a, b, (tx, ty) = translated_pair(h, w, 50000 + i, max_shift=5)
+    if i % 3 == 0:      # a third of the cases on the FPV-like warped family (non-uniform sub-pixel flow + occluder)
+        a, b, gt, _ = warped_pair(h, w, 50000 + i, zoom=float(rng.uniform(0.96, 1.08)), angle_deg=float(rng.uniform(-4, 4)),
+                                  shift=(float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4))))
+        tx, ty = (float(v) for v in gt[h // 2, w // 2])
+    else:
+        a, b, (tx, ty) = translated_pair(h, w, 50000 + i, max_shift=5)
     init = None
     if kw["flags"] & 4:
         init = (np.array([tx, ty], np.float32) + rng.standard_normal((h, w, 2)).astype(np.float32)).astype(np.float32)
@@ -31,4 +36,6 @@ for i in range(N):
     if not np.array_equal(got, ref):
         bad += 1
         print("MISMATCH", w, h, kw, os.environ["OFARN_DIRECT_MIN_FRAMES"], float(np.abs(got - ref).max()), flush=True)
+    if (i + 1) % 100 == 0:
+        print("...", i + 1, "cases,", bad, "mismatches", flush=True)
 print("cases", N, "mismatches", bad)
