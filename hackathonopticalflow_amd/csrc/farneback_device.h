@@ -24,6 +24,18 @@ __device__ __forceinline__ void load_r(const float *__restrict__ Rf, size_t npx,
     out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
     out[4] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(Rf + 4 * npx) + o * 4u);
 }
+// Non-temporal variant of the R store.  A level's R (20 B per pixel and frame) is written once and read back by a LATER
+// kernel; when a wave's worth of it is far larger than the 256 MB Infinity Cache none of it survives until then, and the `nt`
+// hint lets the write stream pass without allocating there: the level-0 polynomial expansion runs 6.3 -> 5.9 ms per 512 frames
+// with it (same box, alternating runs).  At the coarse levels, whose R does fit, plain stores stay (the launcher decides by
+// size); the 8-B flow stores of the fused iteration measured the same with and without the hint and keep plain stores.
+typedef float ofarn_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_r_nt(float *__restrict__ Rf, size_t npx, unsigned o, const float v[5])
+{
+    const ofarn_f4 t = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<ofarn_f4 *>(reinterpret_cast<char *>(Rf) + o * 16u));
+    __builtin_nontemporal_store(v[4], reinterpret_cast<float *>(reinterpret_cast<char *>(Rf + 4 * npx) + o * 4u));
+}
 __device__ __forceinline__ void store_r(float *__restrict__ Rf, size_t npx, unsigned o, const float v[5])
 {
     *reinterpret_cast<float4 *>(reinterpret_cast<char *>(Rf) + o * 16u) = make_float4(v[0], v[1], v[2], v[3]);

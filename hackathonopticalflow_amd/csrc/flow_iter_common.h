@@ -3,6 +3,8 @@
 #pragma once
 #include "farneback_device.h"
 
+#include <cstdlib>
+
 namespace ofarn {
 
 constexpr int FI_THREADS = 256;
@@ -53,6 +55,15 @@ __device__ __forceinline__ void resize_coord(int d, double scale, int ssize, int
     if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
 }
 
+
+// Bytes written by one launch beyond which its stores carry the non-temporal hint (see store_r_nt): 4 x the 256 MB Infinity Cache.
+constexpr size_t kNtStoreBytes = (size_t)1 << 30;
+// OFARN_NT=0 switches the hint off, OFARN_NT=1 forces it on for every launch (A/B measurements on one box)
+inline int nt_hint(size_t bytes)
+{
+    static const int mode = [] { const char *e = getenv("OFARN_NT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    return mode < 0 ? (bytes > kNtStoreBytes) : mode;
+}
 
 // Strip height in `unit`-row steps for a marching kernel (kernels_fast.hip).
 int best_strip_units(int nunits, int unit, int warm, int blocks_per_strip_row, int blocks_per_cu);

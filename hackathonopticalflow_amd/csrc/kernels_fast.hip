@@ -402,7 +402,7 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
 template <int N, int SRC>
 __global__ __launch_bounds__(FI_THREADS) void k_polyexp_march(const void *__restrict__ src, size_t src_stride,
                                                               float *__restrict__ R, int w, int h, int strip_h,
-                                                              PolyCoef c, float k0, float k1, float k2)
+                                                              PolyCoef c, float k0, float k1, float k2, int nt)
 {
     constexpr int TAPS = 2 * N + 1;
     constexpr int OUTW = march_out_width(N);
@@ -474,7 +474,10 @@ __global__ __launch_bounds__(FI_THREADS) void k_polyexp_march(const void *__rest
         // The stores of row y-1 go out HERE, behind the loads of row y+1 and a whole row of arithmetic before the next
         // wait on a load: the compiler's wait for those loads is a plain vmcnt(0), which also waits for every store issued
         // before it -- stores issued at the end of a row would be waited for at once, with their full write latency exposed.
-        if (y > y0 && writer) store_r(out, npx, (unsigned)(y - 1) * (unsigned)w + (unsigned)x, pv);
+        if (y > y0 && writer) {
+            if (nt) store_r_nt(out, npx, (unsigned)(y - 1) * (unsigned)w + (unsigned)x, pv);
+            else store_r(out, npx, (unsigned)(y - 1) * (unsigned)w + (unsigned)x, pv);
+        }
 #pragma unroll
         for (int j = 0; j < TAPS - 1; j++) win[j] = win[j + 1];
         win[TAPS - 1] = v;
@@ -516,7 +519,10 @@ __global__ __launch_bounds__(FI_THREADS) void k_polyexp_march(const void *__rest
         }
         buf ^= 1;
     }
-    if (y1 > y0 && writer) store_r(out, npx, (unsigned)(y1 - 1) * (unsigned)w + (unsigned)x, pv);
+    if (y1 > y0 && writer) {
+        if (nt) store_r_nt(out, npx, (unsigned)(y1 - 1) * (unsigned)w + (unsigned)x, pv);
+        else store_r(out, npx, (unsigned)(y1 - 1) * (unsigned)w + (unsigned)x, pv);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1027,12 +1033,13 @@ static void launch_polyexp_march_n(hipStream_t s, const void *src, size_t src_st
     constexpr int OUTW = march_out_width(N);
     const int strip_h = best_strip_units(h, 1, 2 * N, (int)cdivu(w, OUTW) * nframes, 6);
     dim3 grid(cdivu(w, OUTW), cdivu(h, strip_h), nframes);
+    const int nt = nt_hint((size_t)nframes * w * h * 20);
     if (src_is_u8)
         hipLaunchKernelGGL((k_polyexp_march<N, 1>), grid, dim3(FI_THREADS), 0, s, src, src_stride, R, w, h, strip_h, c,
-                           blur3[0], blur3[1], blur3[2]);
+                           blur3[0], blur3[1], blur3[2], nt);
     else
         hipLaunchKernelGGL((k_polyexp_march<N, 0>), grid, dim3(FI_THREADS), 0, s, src, src_stride, R, w, h, strip_h, c,
-                           0.f, 0.f, 0.f);
+                           0.f, 0.f, 0.f, nt);
 }
 
 // src_is_u8 = 1: level 0, src = uint8 frames (stride in bytes = elements); else float level images.
