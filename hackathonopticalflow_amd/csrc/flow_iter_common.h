@@ -35,8 +35,6 @@ struct UpsampleArgs {
     int cw, ch;
     const int *xofs;
     const float *xa;
-    const int *yofs;        // (unused by the kernel: the row table is recomputed per row, see resize_coord)
-    const float *ya;
     double yscale;          // 1 / ((double)h / ch): resize.cpp's `scale` of the vertical axis
     float mul;
     unsigned long long *dbg;   // OFARN_STAMPS diagnostic build only: per-segment cycle sums

@@ -946,7 +946,8 @@ static void launch_flow_iter_m(hipStream_t s, const float *R, int fstep, const f
     const double scale = 1. / ((double)winsize * winsize);
     // resize_tables(): inv_scale = (double)dsize / ssize; scale = 1. / inv_scale
     const double yscale = ch > 0 ? 1. / ((double)h / ch) : 1.;
-    UpsampleArgs up{reinterpret_cast<const float2 *>(coarse), cw, ch, d_xofs, d_xa, d_yofs, d_ya, yscale, mul, nullptr};
+    (void)d_yofs; (void)d_ya;     // the row table is recomputed in the kernel (resize_coord)
+    UpsampleArgs up{reinterpret_cast<const float2 *>(coarse), cw, ch, d_xofs, d_xa, yscale, mul, nullptr};
 #ifdef OFARN_STAMPS
     static unsigned long long *dbg = nullptr;
     static int calls = 0;

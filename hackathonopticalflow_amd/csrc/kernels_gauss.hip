@@ -230,7 +230,8 @@ static void launch_flow_iter_gauss_mm(hipStream_t s, const float *R, int fstep, 
     const int strip_h = best_strip_units(h, 1, B - 1, (int)((w + OUTW - 1) / OUTW) * npairs, gauss_blocks_per_cu<M_, MODE>());
     dim3 grid((unsigned)((w + OUTW - 1) / OUTW), (unsigned)((h + strip_h - 1) / strip_h), npairs);
     const double yscale = ch > 0 ? 1. / ((double)h / ch) : 1.;
-    UpsampleArgs up{reinterpret_cast<const float2 *>(coarse), cw, ch, d_xofs, d_xa, d_yofs, d_ya, yscale, mul, nullptr};
+    (void)d_yofs; (void)d_ya;     // the row table is recomputed in the kernel (resize_coord)
+    UpsampleArgs up{reinterpret_cast<const float2 *>(coarse), cw, ch, d_xofs, d_xa, yscale, mul, nullptr};
     hipLaunchKernelGGL((k_flow_iter_gauss<M_, MODE>), grid, dim3(FI_THREADS), 0, s, R, fstep, reinterpret_cast<const float2 *>(flow_in),
                        reinterpret_cast<float2 *>(flow_out), w, h, strip_h, taps, up);
 }
