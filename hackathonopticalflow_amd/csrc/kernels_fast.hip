@@ -3,7 +3,7 @@
 // k_flow_iter: one Farneback iteration = FarnebackUpdateMatrices + FarnebackUpdateFlow_Blur fused
 // (stages C + D; with MODE 1 also stage E, the flow upsample).  M never goes to HBM.
 //
-//   * A block of 256 threads owns a strip of 256-2m columns (m = winsize/2) plus an m-column halo
+//   * A block of 256 threads owns a strip of march_out_width(m) columns (240 for m = winsize/2 = 7) plus an m-column halo
 //     on each side, one thread per column, and MARCHES down `strip_h` rows.
 //   * Each thread computes G11,G12,G22,h1,h2 for its column at row y+m (bilinear gather of R1,
 //     combine with R0, border damping) and keeps the last 2m+1 rows of its column in registers:
@@ -19,7 +19,7 @@
 // results equal the unfused generic kernels and the CPU oracle bit for bit.
 //
 // Roofline: HBM-bound by design: per pixel and iteration it reads flow 8 B + R0 20 B + R1 20 B
-// (gathered, mostly sequential) and writes 8 B, x (256/(256-2m)) x ((strip_h+2m)/strip_h) halo
+// (gathered, mostly sequential) and writes 8 B, x ((240+2m)/240) x ((strip_h+2m)/strip_h) halo
 // re-reads that L2 mostly absorbs; ~150 f64 adds per pixel keep the f64 pipe about half busy.
 #include "farneback_device.h"
 #include "flow_iter_common.h"
@@ -394,7 +394,7 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
 //   SRC 1: level 0 fused with stage A: reads the uint8 frame and applies the 3-tap Gaussian
 //          ([1/4,1/2,1/4], BORDER_REFLECT_101, row pass then column pass) on the fly -- at scale 1
 //          resize() is the identity, so the level image never exists in HBM.
-// One thread per column (256-2N outputs per block row), marching down strip_h rows with the last
+// One thread per column (march_out_width(N) = 240 outputs per block row), marching down strip_h rows with the last
 // 2N+1 level-image values of its column in registers: the float32 vertical pass is private, the
 // (r0, r1, r2) line is exchanged through a double-buffered LDS line, the horizontal pass
 // accumulates in double in optflowgf.cpp's order.  Bit-identical to k_polyexp / the oracle.

@@ -1,7 +1,7 @@
 // kernels_gauss.hip -- fused Farneback iteration with the Gaussian window (flags & OPTFLOW_FARNEBACK_GAUSSIAN):
 // FarnebackUpdateMatrices + FarnebackUpdateFlow_GaussianBlur of one iteration in one kernel, M never in HBM.
 //
-// Same marching structure as k_flow_iter (kernels_fast.hip): a block of 256 threads owns 256-2m output columns plus an
+// Same marching structure as k_flow_iter (kernels_fast.hip): a block of 256 threads owns march_out_width(m) output columns plus an
 // m-column halo per side, one thread per column, marching down a strip; the gather of the next matrix row is in flight
 // while the current row is processed.  What differs is the window arithmetic (optflowgf.cpp, float32 throughout):
 //   column pass  s0 = M[y]*k[0];   s0 = s0 + (M[y+i] + M[y-i]) * k[i]       i = 1..m   (rows clamped: replicate border)
