@@ -65,5 +65,6 @@ inline int nt_hint(size_t bytes)
 
 // Strip height in `unit`-row steps for a marching kernel (kernels_fast.hip).
 int best_strip_units(int nunits, int unit, int warm, int blocks_per_strip_row, int blocks_per_cu);
+int march_cu_count();   // CUs of the current device
 
 }  // namespace ofarn

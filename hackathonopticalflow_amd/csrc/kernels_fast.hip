@@ -943,6 +943,12 @@ static void launch_flow_iter_m(hipStream_t s, const float *R, int fstep, const f
     const int nblk = (h + B - 1) / B;
     const int strip_h = B * best_strip_units(nblk, B, B - 1, (int)cdivu(w, OUTW) * npairs, 3);
     dim3 grid(cdivu(w, OUTW), cdivu(h, strip_h), npairs);
+    // a grid that leaves most CUs without a block is latency bound: the tile kernel (kernels_tile.hip) does the same arithmetic
+    // with all of a tile's gathers in flight at once
+    if (flow_iter_tile_supported(winsize) && flow_iter_tile_preferred((long)grid.x * grid.y * grid.z)) {
+        launch_flow_iter_tile(s, R, fstep, flow_in, flow_out, w, h, npairs, winsize, mode, coarse, cw, ch, d_xofs, d_xa, mul);
+        return;
+    }
     const double scale = 1. / ((double)winsize * winsize);
     // resize_tables(): inv_scale = (double)dsize / ssize; scale = 1. / inv_scale
     const double yscale = ch > 0 ? 1. / ((double)h / ch) : 1.;
@@ -999,9 +1005,9 @@ namespace ofarn {
 
 // Strip height in `unit`-row steps for a marching kernel: each block marches strip + warm rows, the
 // GPU holds blocks_per_cu * CUs blocks at once; minimise ceil(blocks / resident) * rows-per-block.
-int best_strip_units(int nunits, int unit, int warm, int blocks_per_strip_row, int blocks_per_cu)
+// CU count of the CURRENT device, cached per device ordinal (a process may drive several GPUs)
+int march_cu_count()
 {
-    // CU count of the CURRENT device, cached per device ordinal (a process may drive several GPUs)
     static int ncu_of[64] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -1012,6 +1018,12 @@ int best_strip_units(int nunits, int unit, int warm, int blocks_per_strip_row, i
         ncu = v;
         __atomic_store_n(&ncu_of[dev], v, __ATOMIC_RELAXED);
     }
+    return ncu;
+}
+
+int best_strip_units(int nunits, int unit, int warm, int blocks_per_strip_row, int blocks_per_cu)
+{
+    const int ncu = march_cu_count();
     const long resident = (long)ncu * blocks_per_cu;
     long best_cost = -1;
     int best = nunits;

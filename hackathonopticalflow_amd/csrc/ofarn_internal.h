@@ -63,6 +63,13 @@ bool flow_iter_supported(int winsize);
 void launch_flow_iter(hipStream_t s, const float *R, int fstep, const float *flow_in, float *flow_out, int w,
                       int h, int npairs, int winsize, int mode, const float *coarse, int cw, int ch,
                       const int *d_xofs, const float *d_xa, const int *d_yofs, const float *d_ya, float mul);
+// The same iteration laid out for latency (kernels_tile.hip): chosen by launch_flow_iter when the marching grid would leave
+// most of the chip empty (a single pair, coarse levels of a small batch).  Bit-identical results.
+bool flow_iter_tile_supported(int winsize);
+bool flow_iter_tile_preferred(long marching_blocks);
+void launch_flow_iter_tile(hipStream_t s, const float *R, int fstep, const float *flow_in, float *flow_out, int w, int h,
+                           int npairs, int winsize, int mode, const float *coarse, int cw, int ch, const int *d_xofs,
+                           const float *d_xa, float mul);
 // The same with the Gaussian window of OPTFLOW_FARNEBACK_GAUSSIAN (kernels_gauss.hip); h_kern: host pointer to the m+1 taps.
 bool flow_iter_gauss_supported(int winsize);
 void launch_flow_iter_gauss(hipStream_t s, const float *R, int fstep, const float *flow_in, float *flow_out, int w, int h,

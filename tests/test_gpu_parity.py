@@ -38,6 +38,15 @@ def H():
     return H
 
 
+@pytest.fixture(params=["march", "tile"])
+def iter_kernel(request, monkeypatch):
+    """The fused iteration exists twice with identical results: the marching kernel (throughput; chosen when its grid fills
+    the chip) and the tile kernel (latency; chosen for small grids).  Left alone, a single small pair would only ever reach
+    the tile kernel, so the pipeline tests force each in turn (OFARN_TILE is read per launch)."""
+    monkeypatch.setenv("OFARN_TILE", "0" if request.param == "march" else "1")
+    return request.param
+
+
 def epe(a, b):
     return np.linalg.norm(a.astype(np.float64) - b.astype(np.float64), axis=-1)
 
@@ -123,7 +132,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("w,h,seed,kw", CASES)
-def test_pipeline_vs_oracle(H, oracle, w, h, seed, kw):
+def test_pipeline_vs_oracle(H, oracle, iter_kernel, w, h, seed, kw):
     prev, nxt, _ = translated_pair(h, w, seed, max_shift=5)
     got = H.calculate_optical_flow(prev, nxt, **kw)
     assert got.shape == (h, w, 2) and got.dtype == np.float32
@@ -170,7 +179,7 @@ def test_generic_and_fused_paths_agree(H, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("w,h", [(9, 7), (33, 17), (16, 64), (257, 3), (5, 300), (1, 1), (40, 1), (1, 40)])
-def test_degenerate_sizes(H, oracle, w, h):
+def test_degenerate_sizes(H, oracle, iter_kernel, w, h):
     rng = np.random.default_rng(w * 1000 + h)
     prev = rng.integers(0, 256, (h, w)).astype(np.uint8)
     nxt = rng.integers(0, 256, (h, w)).astype(np.uint8)
@@ -179,7 +188,7 @@ def test_degenerate_sizes(H, oracle, w, h):
         np.testing.assert_array_equal(got, oracle.farneback(prev, nxt, box_mode=oracle.BOX_BLOCKED, **kw))
 
 
-def test_pipeline_1080p_L5_config2(H, oracle):
+def test_pipeline_1080p_L5_config2(H, oracle, iter_kernel):
     """BASELINE config 2: one 1920x1080 pair, levels=5, iterations=3, seed 2001."""
     prev, nxt, (tx, ty) = translated_pair(1080, 1920, 2001)
     got = H.calculate_optical_flow(prev, nxt, levels=5)
@@ -223,7 +232,7 @@ def test_full_size_properties_config3(H):
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
-def test_golden_fixtures(H, path):
+def test_golden_fixtures(H, iter_kernel, path):
     g = np.load(path, allow_pickle=False)
     kw = dict(ast.literal_eval(str(g["params"])))
     got = H.calculate_optical_flow(g["prev"], g["next"], **kw)
@@ -276,7 +285,7 @@ def test_strided_input(H, oracle):
 
 
 # ------------------------------------------------------------------------------------ batch + danger map
-def test_batch_modes_and_waves(H, oracle):
+def test_batch_modes_and_waves(H, oracle, iter_kernel):
     h, w, n_pairs = 120, 160, 5
     frames, _ = translated_pairs(n_pairs, h, w, 3000, max_shift=4)
     kw = dict(levels=2)
@@ -474,7 +483,7 @@ def test_stage_resize_area_bit_exact(H, oracle, sw, sh, dw, dh):
 @pytest.mark.parametrize("w,h,kw", [(320, 240, dict(levels=3)), (333, 251, dict(levels=2, winsize=9, iterations=2)),
                                     (160, 120, dict(levels=0)), (200, 150, dict(levels=1, iterations=1)),
                                     (256, 192, dict(levels=2, flags=256))])
-def test_use_initial_flow(H, oracle, w, h, kw, monkeypatch):
+def test_use_initial_flow(H, oracle, iter_kernel, w, h, kw, monkeypatch):
     kw = dict(kw)
     flags = kw.pop("flags", 0) | H.OPTFLOW_USE_INITIAL_FLOW
     a, b, (tx, ty) = translated_pair(h, w, 31, max_shift=4)
@@ -735,7 +744,7 @@ def _fuzz_cases(n, seed):
 
 
 @pytest.mark.parametrize("w,h,seed,kw", _fuzz_cases(36, 20261004))
-def test_fuzz_pipeline_bit_exact(H, oracle, w, h, seed, kw, monkeypatch):
+def test_fuzz_pipeline_bit_exact(H, oracle, iter_kernel, w, h, seed, kw, monkeypatch):
     """Random sizes and parameter sets (fused, generic, direct-level and flag paths all get hit): the whole pipeline
     bit for bit against the oracle in the device summation order."""
     monkeypatch.setenv("OFARN_DIRECT_MIN_FRAMES", "1" if seed % 2 else "32")
@@ -822,7 +831,7 @@ WARP_CASES = [
 
 
 @pytest.mark.parametrize("w,h,seed,wkw,kw", WARP_CASES)
-def test_pipeline_warped_family(H, oracle, w, h, seed, wkw, kw):
+def test_pipeline_warped_family(H, oracle, iter_kernel, w, h, seed, wkw, kw):
     """Zoom + rotation + sub-pixel shift + occluding patch: the flow-dependent gather of FarnebackUpdateMatrices is
     unaligned and, along the borders the flow points out of, takes its out-of-image branch row after row."""
     a, b, gt, valid = warped_pair(h, w, seed, **wkw)
