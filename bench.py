@@ -266,7 +266,7 @@ def bench_latency(args, cfg, params):
         "config": {"workload": f"config2: one 1920x1080 {args.family} pair through ofarn_calc (host pointers: 4 MB in, 16.6 MB out over "
                                f"PCIe inside the timed call), levels=5 iterations=3 winsize=15 poly_n=5", "global_pairs": 1},
         "device_ms": round(dms, 4), "wall_ms_min": round(min(ts), 4), "pairs_per_s_wall": round(1e3 / float(np.median(ts)), 1),
-        "roofline": {"bound": "launch latency (about 40 short kernels, the three coarsest levels are a few thousand pixels)",
+        "roofline": {"bound": "latency (30 dependent launches; all but the finest level are grids of a few blocks)",
                      "achieved": round(alg / (dms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                      "algorithmic_bytes_per_pair": alg},
