@@ -374,3 +374,25 @@ def test_rejects_bad_arguments(oracle):
         oracle.farneback(p, n, flags=4)       # OPTFLOW_USE_INITIAL_FLOW is not restated
     with pytest.raises(ValueError):
         oracle.farneback(p, n, winsize=1)
+
+
+@pytest.mark.parametrize("zoom,angle,shift", [(1.03, 0.8, (1.6, -0.7)), (0.97, -2.0, (-2.3, 1.1)), (1.06, 0.0, (0.0, 0.0))])
+def test_warped_family_ground_truth(oracle, zoom, angle, shift):
+    """The FPV-like input family (synth.warped_pair: zoom about a focus + rotation + sub-pixel shift + an occluding patch that
+    moves on its own): the oracle's flow follows the analytic ground truth away from the borders and the patch, the radial field
+    really is non-uniform, and the three box-filter summation orders still agree to 1e-4 px on it."""
+    from hackathonopticalflow_amd.synth import warped_pair
+    h, w = 270, 480
+    a, b, gt, valid = warped_pair(h, w, 77, zoom=zoom, angle_deg=angle, shift=shift)
+    assert a.dtype == np.uint8 and a.shape == (h, w) and gt.shape == (h, w, 2)
+    flow = oracle.farneback(a, b, levels=3)
+    inner = valid.copy()
+    inner[:34] = inner[-34:] = False
+    inner[:, :34] = inner[:, -34:] = False
+    e = np.linalg.norm(flow - gt, axis=-1)
+    assert e[inner].mean() < 0.35, e[inner].mean()
+    if zoom != 1.0:
+        spread = np.linalg.norm(gt[inner] - gt[inner].mean(0), axis=-1).max()
+        assert spread > 3.0                                     # several pixels of variation across the frame
+    d = np.linalg.norm(flow - oracle.farneback(a, b, levels=3, box_mode=oracle.BOX_BLOCKED), axis=-1)
+    assert d.max() < 1e-4
