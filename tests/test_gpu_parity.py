@@ -1031,3 +1031,22 @@ def test_workspace_grows_on_demand_and_fails_cleanly(H, oracle, monkeypatch):
     monkeypatch.delenv("OFARN_FORCE_GENERIC")
     with pytest.raises(MemoryError):
         H.FarnebackEngine(3840, 2160, 4000)          # 4000 pairs of 4K: ~2 TB of R alone
+
+
+def test_c_program_through_the_c_abi(H, tmp_path):
+    """The boundary without Python: examples/c_abi_pair.c (plain C99, links libofarn.so) reads two raw frames, calls ofarn_create /
+    ofarn_calc / ofarn_grid_filter and writes the flow; it must equal the Python mirror's result bit for bit."""
+    import subprocess
+    from test_host_abi import _build_c_example
+    exe = _build_c_example(tmp_path)
+    h, w = 270, 480
+    a, b, _, _ = warped_pair(h, w, 4321)
+    (tmp_path / "frames.raw").write_bytes(a.tobytes() + b.tobytes())
+    r = subprocess.run([exe, str(tmp_path / "frames.raw"), str(w), str(h), str(tmp_path / "flow.raw"), "3"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    flow_c = np.fromfile(tmp_path / "flow.raw", np.float32).reshape(h, w, 2)
+    flow_py = H.calculate_optical_flow(a, b, levels=3)
+    np.testing.assert_array_equal(flow_c, flow_py)
+    mask, _ = H.danger_map(flow_py, 30)
+    assert f"danger points: {int(mask.sum())} of {mask.size} grid points" in r.stdout

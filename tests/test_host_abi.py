@@ -121,3 +121,24 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "from oracle" not in txt and "import oracle" not in txt and "libofarn_oracle" not in txt, f
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    from hackathonopticalflow_amd import build as hb
+    exe = str(tmp_path / "c_abi_pair")
+    libdir = os.path.dirname(hb.LIB)
+    cmd = ["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "c_abi_pair.c"), "-o", exe, "-L" + libdir, "-lofarn", "-Wl,-rpath," + libdir]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_c_abi_header_is_plain_c_and_links(tmp_path):
+    """include/ofarn.h must be usable from C (no C++ or torch types): examples/c_abi_pair.c, a C99 program, compiles against it
+    with -Wall -Wextra -Werror and links with libofarn.so.  Without arguments it prints its usage and exits with 2 (no GPU call)."""
+    import subprocess
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
