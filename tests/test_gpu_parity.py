@@ -1050,3 +1050,31 @@ def test_c_program_through_the_c_abi(H, tmp_path):
     np.testing.assert_array_equal(flow_c, flow_py)
     mask, _ = H.danger_map(flow_py, 30)
     assert f"danger points: {int(mask.sum())} of {mask.size} grid points" in r.stdout
+
+
+def test_contexts_give_their_memory_back(H):
+    """ofarn_destroy frees everything a context ever allocated: workspace (eager and grown on demand), staging, plan tables,
+    the LK pyramid, streams and events.  Free device memory after 20 create / use / destroy cycles equals what it was before."""
+    torch = pytest.importorskip("torch")
+    a, b, _ = translated_pair(240, 320, 71, max_shift=3)
+    frames, _ = translated_pairs(3, 240, 320, 72, max_shift=3)
+    pts = H.grid_points(320, 240, 30)
+    H.close_cached_engines()
+
+    def cycle(flags):
+        with H.FarnebackEngine(320, 240, 2, levels=2, flags=flags) as eng:
+            eng.calc(a, b, np.zeros((240, 320, 2), np.float32) if flags & 4 else None)
+            eng.calc_batch(frames, H.PAIRS_INDEPENDENT, init_flow=np.zeros((3, 240, 320, 2), np.float32) if flags & 4 else None)
+            eng.danger_map(np.zeros((240, 320, 2), np.float32))
+            eng.lk(a, b, pts)
+            eng.bgr2gray(np.zeros((240, 320, 3), np.uint8))
+            eng.stage_blur_solve(np.zeros((240, 320, 5), np.float32))
+
+    cycle(0)                                  # first use: module load, runtime pools
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for i in range(20):
+        cycle((0, 4, 256, 260)[i % 4])
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free0 - free1) <= 8 << 20, (free0, free1)       # nothing held back (allocator granularity aside)
