@@ -645,36 +645,44 @@ class _CachedEngine:
 
 
 class _EngineLease:
-    """``with _engine_for(...) as eng:`` -- holds the entry's lock for the duration of the call."""
+    """``with _engine_for(...) as eng:`` -- holds the entry's lock for the duration of the call.  An entry can be evicted
+    (and closed) by another thread between the lookup and the lock; the lease then simply looks the key up again."""
 
-    def __init__(self, entry):
-        self._entry = entry
+    def __init__(self, key, h, w, device, params):
+        self._key, self._h, self._w, self._device, self._params = key, h, w, device, params
+        self._entry = None
+
+    def _lookup(self):
+        evicted = None
+        with _engines_lock:
+            entry = _engines.get(self._key)
+            if entry is None:
+                if len(_engines) >= 8:   # bounded cache: drop the oldest context
+                    evicted = _engines.pop(next(iter(_engines)))
+                entry = _engines[self._key] = _CachedEngine(FarnebackEngine(self._w, self._h, 1, self._device, **self._params))
+        if evicted is not None:
+            with evicted.lock:           # waits for a thread that is still inside a call on it
+                if evicted.eng is not None:
+                    evicted.eng.close()
+                    evicted.eng = None
+        return entry
 
     def __enter__(self) -> FarnebackEngine:
-        self._entry.lock.acquire()
-        if self._entry.eng is None:                       # evicted between lookup and use: rare, just fail loudly
-            self._entry.lock.release()
-            raise RuntimeError("cached engine was closed concurrently; retry the call")
-        return self._entry.eng
+        while True:
+            entry = self._lookup()
+            entry.lock.acquire()
+            if entry.eng is not None:
+                self._entry = entry
+                return entry.eng
+            entry.lock.release()         # closed by an eviction that won the race: look it up (create it) again
 
     def __exit__(self, *a):
         self._entry.lock.release()
+        self._entry = None
 
 
 def _engine_for(h, w, device, **params) -> _EngineLease:
-    key = (h, w, device, tuple(sorted(params.items())))
-    evicted = None
-    with _engines_lock:
-        entry = _engines.get(key)
-        if entry is None:
-            if len(_engines) >= 8:   # bounded cache: drop the oldest context
-                evicted = _engines.pop(next(iter(_engines)))
-            entry = _engines[key] = _CachedEngine(FarnebackEngine(w, h, 1, device, **params))
-    if evicted is not None:
-        with evicted.lock:           # waits for a thread that is still inside a call on it
-            evicted.eng.close()
-            evicted.eng = None
-    return _EngineLease(entry)
+    return _EngineLease((h, w, device, tuple(sorted(params.items()))), h, w, device, params)
 
 
 def calculate_optical_flow(prev, next, flow=None, pyr_scale=0.5, levels=3, winsize=15, iterations=3,

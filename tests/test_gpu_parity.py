@@ -1078,3 +1078,33 @@ def test_contexts_give_their_memory_back(H):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert abs(free0 - free1) <= 8 << 20, (free0, free1)       # nothing held back (allocator granularity aside)
+
+
+def test_drop_in_call_from_several_threads(H, oracle):
+    """the cache behind calculate_optical_flow() holds 8 contexts and used to close the oldest while another thread
+    could be inside it.  Four threads call the drop-in function with twelve different frame sizes (so entries are evicted all the
+    time) and with shared sizes (so threads meet on one context): every result must be right and nothing may crash."""
+    import threading
+    sizes = [(96 + 8 * i, 64 + 8 * (i % 5)) for i in range(12)]
+    pairs = {s: translated_pair(s[1], s[0], 500 + i, max_shift=3)[:2] for i, s in enumerate(sizes)}
+    refs = {s: oracle.farneback(p[0], p[1], levels=1, box_mode=oracle.BOX_BLOCKED) for s, p in pairs.items()}
+    errors = []
+
+    def worker(k):
+        try:
+            rng = np.random.default_rng(k)
+            for _ in range(30):
+                s = sizes[int(rng.integers(0, len(sizes)))]
+                got = H.calculate_optical_flow(pairs[s][0], pairs[s][1], levels=1)
+                if not np.array_equal(got, refs[s]):
+                    errors.append(("mismatch", s))
+        except Exception as e:      # noqa: BLE001
+            errors.append(("exception", repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    H.close_cached_engines()
