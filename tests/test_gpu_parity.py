@@ -1108,3 +1108,55 @@ def test_drop_in_call_from_several_threads(H, oracle):
         t.join()
     assert not errors, errors[:3]
     H.close_cached_engines()
+
+
+@pytest.mark.parametrize("w,h,kw", [
+    (4096, 96, dict(levels=1)),                       # wide and flat
+    (96, 4096, dict(levels=1)),                       # narrow and tall: many strips, one column block
+    (300, 200, dict(levels=4, pyr_scale=0.3)),        # steep pyramid: cropped to the levels that stay >= 32 px
+    (300, 200, dict(levels=3, pyr_scale=0.95)),       # nearly flat pyramid: no level is a power-of-two fraction
+    (200, 150, dict(levels=2, iterations=0)),         # no iterations: the flow is only initialised and upsampled
+    (200, 150, dict(levels=0, iterations=6)),         # one scale, many iterations
+    (257, 131, dict(levels=2, winsize=2)),            # smallest window
+    (160, 120, dict(levels=1, poly_n=1, poly_sigma=0.0)),   # smallest polynomial support, sigma from n
+])
+def test_unusual_shapes_and_parameters(H, oracle, w, h, kw):
+    a, b, _ = translated_pair(h, w, 600 + w % 97, max_shift=3)
+    got = H.calculate_optical_flow(a, b, **kw)
+    np.testing.assert_array_equal(got, oracle.farneback(a, b, box_mode=oracle.BOX_BLOCKED, **kw))
+
+
+def test_two_contexts_from_two_threads(H, oracle):
+    """Contexts are independent: two threads, each with its own engine (different parameters, same GPU), run at the same time."""
+    import threading
+    a, b, _ = translated_pair(240, 320, 81, max_shift=3)
+    frames, _ = translated_pairs(6, 240, 320, 82, max_shift=3)
+    ref1 = oracle.farneback(a, b, levels=2, box_mode=oracle.BOX_BLOCKED)
+    ref2 = [oracle.farneback(frames[2 * i], frames[2 * i + 1], levels=3, winsize=9, box_mode=oracle.BOX_BLOCKED) for i in range(6)]
+    errors = []
+
+    def single():
+        try:
+            with H.FarnebackEngine(320, 240, 1, levels=2) as eng:
+                for _ in range(15):
+                    if not np.array_equal(eng.calc(a, b), ref1):
+                        errors.append("single")
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    def batch():
+        try:
+            with H.FarnebackEngine(320, 240, 4, levels=3, winsize=9) as eng:
+                for _ in range(5):
+                    flow, _, _ = eng.calc_batch(frames, H.PAIRS_INDEPENDENT, want_danger=False)
+                    if not all(np.array_equal(flow[i], ref2[i]) for i in range(6)):
+                        errors.append("batch")
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=single), threading.Thread(target=batch)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:3]
