@@ -2,10 +2,11 @@
 """Offline randomized parity sweep (bigger than the seeded fuzz in tests/): random sizes, parameters and flags through the
 whole dense pipeline on the GPU, compared bit for bit with the CPU oracle in the device summation order.
 
-    python tools/bigfuzz.py [seed] [cases]          (needs an MI355X; imports oracle/ as the checker)
+    python tests/bigfuzz_offline.py [seed] [cases]    (needs an MI355X; test infrastructure: imports oracle/ as the checker.
+                                                       Not collected by pytest -- the seeded fuzz cases in test_gpu_parity.py are)
 """
 import sys, os
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import hackathonopticalflow_amd as H
 from hackathonopticalflow_amd.synth import translated_pair, warped_pair

@@ -178,3 +178,18 @@ def test_no_kernel_uses_scratch_memory(tmp_path):
     assert len(kernels) > 60, len(kernels)                                   # all instantiations were found
     bad = {k: v for k, v in kernels.items() if v != (0, 0)}
     assert not bad, bad
+
+
+def test_only_tests_bench_and_smoke_touch_the_oracle():
+    """oracle/ is test infrastructure: besides tests/, only bench.py (its cpu_baseline / parity leg) and __graft_entry__ (build +
+    smoke) may import it -- no tool, example or product module."""
+    import glob
+    offenders = []
+    for path in glob.glob(os.path.join(ROOT, "**", "*.py"), recursive=True):
+        rel = os.path.relpath(path, ROOT)
+        if rel.startswith(("tests" + os.sep, "oracle" + os.sep, "gpurun_out" + os.sep)) or rel in ("bench.py", "__graft_entry__.py"):
+            continue
+        src = open(path, encoding="utf-8").read()
+        if re.search(r"^\s*(from\s+oracle\b|import\s+oracle\b)", src, re.M):
+            offenders.append(rel)
+    assert not offenders, offenders

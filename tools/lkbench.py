@@ -18,7 +18,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--cpu", type=int, default=2, help="pairs timed on the CPU oracle (0 = skip)")
     a = ap.parse_args()
     import torch
     import hackathonopticalflow_amd as ofa
@@ -54,15 +53,6 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.reps
     print(f"LK + filter, {P} points, winSize 45, maxLevel 2: {dt * 1e3:.2f} ms per {a.batch} pairs -> {a.batch / dt:.1f} pairs/s")
-    if a.cpu:
-        from oracle import oracle as O
-        O.build()
-        f = fr[:2 * min(a.cpu, uniq)]
-        t0 = time.perf_counter()
-        for i in range(len(f) // 2):
-            O.calc_optical_flow_pyr_lk(f[2 * i + 1], f[2 * i], pts, None, winSize=(45, 45), maxLevel=2, criteria=(10, 0.03))
-        dc = (time.perf_counter() - t0) / (len(f) // 2)
-        print(f"CPU oracle (one thread): {dc * 1e3:.1f} ms per pair -> {1 / dc:.2f} pairs/s")
 
 
 if __name__ == "__main__":
