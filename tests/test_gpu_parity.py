@@ -1160,3 +1160,39 @@ def test_two_contexts_from_two_threads(H, oracle):
     for t in ts:
         t.join()
     assert not errors, errors[:3]
+
+
+def test_device_batch_is_graph_capturable(H, oracle):
+    """After one warm-up call (which builds the plan and grows the workspace) a device-resident batch call allocates nothing
+    and synchronises nothing, so it can be captured into a HIP graph and replayed -- including the fork / join over the two
+    internal streams that a batch of several waves uses.  The replayed graph must give the same flow and danger maps."""
+    torch = pytest.importorskip("torch")
+    h, w, n_pairs = 120, 160, 6
+    frames, _ = translated_pairs(n_pairs, h, w, 4700, max_shift=4)
+    other, _ = translated_pairs(n_pairs, h, w, 4800, max_shift=4)
+    P = len(H.grid_points(w, h, 30))
+    d_frames = torch.from_numpy(frames).cuda()
+    d_flow = torch.zeros((n_pairs, h, w, 2), dtype=torch.float32, device="cuda")
+    d_mask = torch.zeros((n_pairs, P), dtype=torch.uint8, device="cuda")
+    d_v = torch.zeros_like(d_mask)
+    side = torch.cuda.Stream()
+    with H.FarnebackEngine(w, h, 4, levels=2) as eng:          # waves of 4 pairs: two waves, two internal streams
+        with torch.cuda.stream(side):
+            eng.calc_batch_device(d_frames, 2 * n_pairs, w, h, H.PAIRS_INDEPENDENT, d_flow, d_mask, d_v, stream=side.cuda_stream)
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            eng.calc_batch_device(d_frames, 2 * n_pairs, w, h, H.PAIRS_INDEPENDENT, d_flow, d_mask, d_v, stream=side.cuda_stream)
+        for src in (other, frames):
+            d_frames.copy_(torch.from_numpy(src).cuda())
+            d_flow.zero_()
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            got = d_flow.cpu().numpy()
+            for i in range(n_pairs):
+                np.testing.assert_array_equal(got[i], oracle.farneback(src[2 * i], src[2 * i + 1], levels=2, box_mode=oracle.BOX_BLOCKED))
+                m_ref, v_ref = oracle.danger_map_numpy(got[i], w, h, 30)
+                np.testing.assert_array_equal(d_mask[i].cpu().numpy(), m_ref)
+                np.testing.assert_array_equal(d_v[i].cpu().numpy(), v_ref)
+        del g
