@@ -59,8 +59,15 @@ STAGE_BYTES = {
     "blur_solve": 28.0,       # M 20 in, flow 8 out
     "flow_upsample": 10.0,    # 8 B out + 8 B/4 in
     "level_vpass": 4.0,       # level image out (the frame read is charged to level_hpass)
-    "flow_iter": 96.0,        # fused C + D: 68 + 28 (M no longer reaches HBM; SURVEY 8(d) keeps the figure)
+    "level_hpass": 8.0,       # row-pass intermediate out: float2 per (frame row, level column); the 1 B/px frame read adds
+                              # 1/8 .. 1/2 B per unit at the levels that take this path (scale 1/16 and below)
+    "flow_iter": 96.0,        # fused C + D as SURVEY 8(d) charges it: C 68 + D 28, i.e. including the 20 B written + 20 B read
+                              # of M that the fused kernel never moves
 }
+# What the fused iteration kernel itself declares: flow 8 + R0 20 + R1 20 in, flow 8 out.  `roofline.achieved` / `frac` use
+# THIS figure for a flow_iter launch (a bandwidth the memory system really has to deliver, so it cannot exceed the peak);
+# the SURVEY 8(d) figure above is reported next to it as `survey_8d_achieved` / `survey_8d_frac`.
+KERNEL_BYTES = dict(STAGE_BYTES, flow_iter=56.0)
 
 
 def algorithmic_bytes_per_pair(w, h, plan, iterations):
@@ -83,7 +90,7 @@ def self_launch(args, argv):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={max(args.gpus, 1)}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -310,6 +317,10 @@ def main():
                     help="skip the informational second measurement with per-kernel timing off (two internal streams)")
     ap.add_argument("--no-family-check", action="store_true",
                     help="skip the informational third measurement on the other input family (data-independence check)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the distributed leg at ANY world size, 1 included: bench.py starts its rank(s) through "
+                         "torch.distributed.run, initialises the process group and all-gathers the danger maps inside the timed "
+                         "region.  `--gpus 1 --backend nccl --force-dist` is how RCCL's all_gather_into_tensor is exercised on a one-GPU box")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (gloo: rehearsal of the multi-rank path with "
                          "several ranks sharing one GPU; the gather then goes through host memory)")
@@ -323,7 +334,7 @@ def main():
         raise SystemExit("--steps, --batch and --wave must be >= 1, --warmup >= 0")
 
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and "RANK" not in os.environ:
+    if (args.gpus > 1 or args.force_dist) and "RANK" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))      # fresh child; this process never initialises HIP
     if env_world != max(args.gpus, 1):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env_world}")
@@ -342,10 +353,17 @@ def main():
 
     rank, local_rank, world = D.env_rank_world()
     W, H = cfg["w"], cfg["h"]
-    dev_index = local_rank % torch.cuda.device_count()     # gloo rehearsal: several ranks share the one GPU of the box
+    ndev = torch.cuda.device_count()
+    share = os.environ.get("OFARN_BENCH_SHARE_GPU") == "1" and args.backend == "gloo"
+    if world > ndev and not share:
+        raise SystemExit(f"{world} ranks but {ndev} GPU(s) visible: one rank per GPU.  (Rehearsing the multi-rank path with several "
+                         f"ranks on one GPU needs OFARN_BENCH_SHARE_GPU=1 and --backend gloo; the line then reports the number of "
+                         f"distinct devices as n_gpus.)")
+    dev_index = local_rank % ndev                           # only ever folds under the gloo rehearsal above
+    n_devices = min(world, ndev)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    dist = D.init_process_group(args.backend) if world > 1 else None
+    dist = D.init_process_group(args.backend, force=args.force_dist) if (world > 1 or args.force_dist) else None
 
     # pairs: config 3 = a fixed batch per GPU (weak); configs 4, 5 = a fixed global batch sharded over the ranks (strong)
     if "per_gpu_pairs" in cfg:
@@ -378,14 +396,13 @@ def main():
     v = torch.zeros((B, P), dtype=torch.uint8, device=device)
     stream = torch.cuda.current_stream().cuda_stream
     gathered = [None]
+    # the one collective of the path, buffers allocated once (device tensors under nccl = RCCL; host tensors under gloo)
+    gather = D.DangerGather(global_pairs, P, device if args.backend == "nccl" else "cpu", dist) if dist is not None else None
 
     def step():
         eng.calc_batch_device(frames, 2 * B, W, H, ofa.PAIRS_INDEPENDENT, flow, mask, v, stream=stream)
-        if dist is not None:
-            if args.backend == "gloo":
-                gathered[0] = D.gather_danger_maps(mask.cpu(), v.cpu(), global_pairs, dist)
-            else:
-                gathered[0] = D.gather_danger_maps(mask, v, global_pairs, dist)
+        if gather is not None:
+            gathered[0] = gather(mask.cpu(), v.cpu()) if args.backend == "gloo" else gather(mask, v)
 
     def fence():
         torch.cuda.synchronize()
@@ -430,7 +447,8 @@ def main():
     # iterations of the other; per-kernel durations lose their meaning there, which is why the timed region above keeps
     # everything on one stream.
     overlapped = None
-    if not args.no_profile and not args.no_two_stream and B >= 64:
+    # (gated on a quantity every rank agrees on: the leg contains collectives)
+    if not args.no_profile and not args.no_two_stream and global_pairs // world >= 64:
         eng_main = eng
         if wave >= B:       # the timed region ran the batch as ONE wave: a second context with waves of B/2 for this leg
             eng = ofa.FarnebackEngine(W, H, (B + 1) // 2, dev_index, **params)
@@ -475,7 +493,7 @@ def main():
     if args.prof_table:
         for r in sorted(prof, key=lambda r: -r["ms"]):
             per = r["ms"] / r["launches"]
-            gbs = STAGE_BYTES.get(r["stage"], 0.0) * r["units"] / r["launches"] / (per * 1e-3) / 1e9
+            gbs = KERNEL_BYTES.get(r["stage"], 0.0) * r["units"] / r["launches"] / (per * 1e-3) / 1e9
             print(f"  {r['stage']:16s} L{r['level']} launches={r['launches']:4d} total={r['ms']:9.3f} ms "
                   f"avg={per:8.4f} ms  alg={gbs:8.1f} GB/s", file=sys.stderr)
     pairs_total = global_pairs * args.steps
@@ -487,8 +505,9 @@ def main():
     if prof:
         dom = max(prof, key=lambda r: r["ms"])
         per_launch_s = dom["ms"] / dom["launches"] / 1e3
-        bytes_launch = STAGE_BYTES.get(dom["stage"], 0.0) * dom["units"] / dom["launches"]
+        bytes_launch = KERNEL_BYTES.get(dom["stage"], 0.0) * dom["units"] / dom["launches"]
         ach = bytes_launch / per_launch_s / 1e9
+        survey_launch = STAGE_BYTES.get(dom["stage"], 0.0) * dom["units"] / dom["launches"]
         # HBM bytes from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as
         # MI355X_MICROARCH.md prescribes; provenance inside profiles/pmc_traffic.json), measured per work unit at
         # level 0 and scaled to this run's units per launch.
@@ -506,6 +525,12 @@ def main():
             "kernel_avg_ms": round(per_launch_s * 1e3, 4), "kernel_launches": dom["launches"],
             "kernel_share_of_device_time": round(dom["ms"] / total_ms, 4),
             "algorithmic_bytes_per_launch": bytes_launch,
+            "algorithmic_bytes_per_unit": KERNEL_BYTES.get(dom["stage"]),
+            # SURVEY 8(d) charges an iteration 96 B per level pixel (C 68 + D 28) whether or not M goes through HBM; the fused
+            # kernel does not move M, so this figure is a work rate, not a bandwidth, and may exceed the peak
+            "survey_8d_bytes_per_launch": survey_launch,
+            "survey_8d_achieved": round(survey_launch / per_launch_s / 1e9, 1),
+            "survey_8d_frac": round(survey_launch / per_launch_s / 1e9 / HBM_PEAK_GBS, 4),
             "pipeline": {
                 "algorithmic_bytes_per_pair": alg_pair,
                 "achieved": round(alg_pair * value / world / 1e9, 1),
@@ -528,19 +553,23 @@ def main():
     out = {
         "metric": f"frame-pairs/s @{'1080p' if W == 1920 else '4K'} ({cfg['levels']}-level, {cfg['iterations']}-iter)",
         "value": round(value, 2), "unit": "pairs/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": n_devices, "ranks": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": cfg["scaling"],
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload + f" ({uniq} distinct, tiled), levels={cfg['levels']} iterations={cfg['iterations']} winsize=15 "
                                f"poly_n=5, f32 with OpenCV's f64 accumulators, flow + danger maps to HBM"
-                               + (f", {args.backend} all-gather of danger maps" if world > 1 else ""),
+                               + (f", {'RCCL' if args.backend == 'nccl' else 'gloo'} all_gather_into_tensor of the danger maps "
+                                  f"inside the timed region ({world} rank(s))" if dist is not None else ""),
                    "pairs_per_gpu": B, "global_pairs": global_pairs, "wave": wave,
                    "workspace_bytes_per_gpu": eng.workspace_bytes,
-                   "parallelism": f"pairs sharded over {world} GPU(s)"},
+                   "parallelism": f"pairs sharded over {world} rank(s) on {n_devices} GPU(s)"
+                                  + (" [ranks share a GPU: gloo rehearsal]" if world > n_devices else "")},
         "roofline": roofline,
     }
     if gather_ok is not None:
         out["gathered_danger_maps_checked"] = gather_ok
+        out["collective"] = {"backend": args.backend, "world": world, "calls": gather.calls,
+                             "bytes_per_rank": int(gather.send.numel()), "device": str(gather.send.device)}
     if overlapped is not None:
         out["two_stream_pairs_per_s"] = round(overlapped, 2)   # per-kernel timing off: waves overlap on two streams (informational)
     if other is not None:

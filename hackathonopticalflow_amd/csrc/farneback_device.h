@@ -12,6 +12,17 @@ __device__ __forceinline__ int reflect101(int p, int len)
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// GaussianBlur row pass of a symmetric float kernel with ksize 3 or 5: filter.simd.hpp SymmRowSmallFilter<float, float>,
+//   ksize 3: S[0]*k0 + (S[-1] + S[1])*k1;   ksize 5: ... + (S[-2] + S[2])*k2      (k0 = centre tap; oracle OFO_ROW_SMALL_SYMM)
+// px: the ksize source values left to right; k: the ksize taps (k[ksize/2] is the centre).
+__device__ __forceinline__ float row_small_symm(const float *px, const float *k, int ksize)
+{
+    const int r = ksize >> 1;
+    float s = px[r] * k[r] + (px[r - 1] + px[r + 1]) * k[r + 1];
+    if (ksize == 5) s = s + (px[0] + px[4]) * k[r + 2];
+    return s;
+}
+
 // R layout ("4+1"): per frame, channels 0..3 of pixel o as one aligned float4 at ((float4*)R)[o],
 // channel 4 as a float at R[4*npx + o].  One 16-byte and one 4-byte load per pixel instead of five
 // 4-byte loads: the texture addresser works per lane and cycle, so wide per-lane loads are what

@@ -285,6 +285,38 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // attribute the whole load wait to segment 0
 #endif
         STAMP(0);
+#ifdef OFARN_EXP_SKELETON
+        // Experiment only (wrong results; `python -m hackathonopticalflow_amd.build --out libofarn_skel.so -DOFARN_EXP_SKELETON=1`,
+        // run with OFARN_LIB): the kernel's address stream -- the flow load two rows ahead, the flow-dependent gather of R1 and
+        // the R0 load one row ahead, the float2 store of output row t-(B-1) -- with the arithmetic replaced by a handful of adds
+        // that consume every loaded dword.  =1: no LDS traffic, no barrier; =2: one LDS line written and read per row behind the
+        // same LDS-only barrier.  What it runs at is what the ACCESS PATTERN can be served at; the gap to the real kernel is
+        // latency / overlap.  The output is a constant sub-pixel flow (+ 0 x the sum) so that the next iteration's gathers
+        // stay as displaced and unaligned as with real data.
+        {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 5; c++) acc += (raw.r0[c] + raw.t00[c]) + (raw.t01[c] + raw.t10[c]) + raw.t11[c];
+            acc += raw.fx + raw.fy;
+            float dx, dy;
+            flow_finish(fr, dx, dy);
+            __builtin_amdgcn_sched_barrier(0);
+            flow_issue(row_of(t + 2 - M_), fr);
+            __builtin_amdgcn_sched_barrier(0);
+            gather_issue(R0, R1, npx, w, h, xc, row_of(t + 1 - M_), dx, dy, raw);
+            __builtin_amdgcn_sched_barrier(0);
+            if (step < B - 1) return;
+#if OFARN_EXP_SKELETON == 2
+            sV[step & 1][0][tid] = (double)acc;
+            barrier_lds_only();
+            acc += (float)sV[step & 1][0][tc - M_] + (float)sV[step & 1][0][tc + M_];
+#endif
+            const float z = acc * 1e-30f;
+            if (writer) stg_f2(fout, ((unsigned)(t - (B - 1)) * (unsigned)w + (unsigned)x) * 8u, make_float2(3.25f + z, -5.5f + z));
+            (void)m; (void)old; (void)j;
+            return;
+        }
+#endif
         matrices_finish(raw, bx, ax, h, row_of(t - M_), m);
         STAMP(1);
         {
@@ -357,6 +389,44 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
         buf ^= 1;
     };
 
+#if defined(OFARN_EXP_SKELETON) && OFARN_EXP_SKELETON == 3
+    // Skeleton with TWO rows of gathers in flight per thread (flow three rows ahead): is the skeleton's rate set by how many
+    // bytes a wave keeps in flight (then this runs faster than =1) or by what the memory system serves the pattern at (then not)?
+    {
+        GatherRaw rawB;
+        {
+            float dx, dy;
+            flow_finish(frA, dx, dy);
+            __builtin_amdgcn_sched_barrier(0);
+            flow_issue(row_of(y0 - M_ + 2), frA);
+            __builtin_amdgcn_sched_barrier(0);
+            gather_issue(R0, R1, npx, w, h, xc, row_of(y0 - M_ + 1), dx, dy, rawB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        auto sk_row = [&](const int step, GatherRaw &raw) {
+            const int t = y0 + step;
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 5; c++) acc += (raw.r0[c] + raw.t00[c]) + (raw.t01[c] + raw.t10[c]) + raw.t11[c];
+            acc += raw.fx + raw.fy;
+            float dx, dy;
+            flow_finish(frA, dx, dy);
+            __builtin_amdgcn_sched_barrier(0);
+            flow_issue(row_of(t + 3 - M_), frA);
+            __builtin_amdgcn_sched_barrier(0);
+            gather_issue(R0, R1, npx, w, h, xc, row_of(t + 2 - M_), dx, dy, raw);
+            __builtin_amdgcn_sched_barrier(0);
+            if (step < B - 1) return;
+            const float z = acc * 1e-30f;
+            if (writer) stg_f2(fout, ((unsigned)(t - (B - 1)) * (unsigned)w + (unsigned)x) * 8u, make_float2(3.25f + z, -5.5f + z));
+        };
+        for (int step = 0; step < nsteps; step += 2) {
+            sk_row(step, rawA);
+            if (step + 1 < nsteps) sk_row(step + 1, rawB);
+        }
+        return;
+    }
+#endif
     {
         using K0 = std::integral_constant<int, 0>;
         using K1 = std::integral_constant<int, 1>;
@@ -371,6 +441,9 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
                 step++;
             }
         }
+#ifdef OFARN_EXP_SKELETON
+        if (false)
+#endif
         if constexpr (H3) {
             // drain: chunk sums of the last row, then the two outstanding window sums
             const int par = nsteps & 1;
@@ -537,7 +610,7 @@ __device__ __forceinline__ int skew(int i) { return i + (i >> 5); }
 __global__ __launch_bounds__(256) void k_level_hpass_lds(const uint8_t *__restrict__ frames, size_t frame_stride,
                                                           int W, int H, const float *__restrict__ kern, int ksize,
                                                           const int *__restrict__ xofs, int dw,
-                                                          float2 *__restrict__ tmp)
+                                                          float2 *__restrict__ tmp, int symm)
 {
     extern __shared__ float srow[];   // skew(W + 2r) floats, then ksize kernel taps
     const int r = ksize >> 1;
@@ -554,6 +627,12 @@ __global__ __launch_bounds__(256) void k_level_hpass_lds(const uint8_t *__restri
         const int sx = xofs[dx];
         const int sx1 = sx + 1 < W ? sx + 1 : W - 1;
         // source column c sits at extended index c + r; tap t reads c - r + t -> extended c + t
+        if (symm && (ksize == 3 || ksize == 5)) {
+            float a[5], b[5];
+            for (int t = 0; t < ksize; t++) { a[t] = srow[skew(sx + t)]; b[t] = srow[skew(sx1 + t)]; }
+            dst[dx] = make_float2(row_small_symm(a, sk, ksize), row_small_symm(b, sk, ksize));
+            continue;
+        }
         float s0 = sk[0] * srow[skew(sx)];
         float s1 = sk[0] * srow[skew(sx1)];
         for (int t = 1; t < ksize; t++) {
@@ -614,7 +693,12 @@ __global__ __launch_bounds__(256) void k_level_hpass_multi(const uint8_t *__rest
             const int sx = lv.xofs[dx];
             const int p = sx - r + rmax;             // extended index of tap 0 of the left column
             float acc0, acc1;
-            if (sx + 1 < W) {
+            if (L.symm && (lv.ksize == 3 || lv.ksize == 5)) {
+                float a[6];
+                for (int t = 0; t <= lv.ksize; t++) a[t] = srow[skew(p + t)];
+                acc0 = row_small_symm(a, kk, lv.ksize);
+                acc1 = sx + 1 < W ? row_small_symm(a + 1, kk, lv.ksize) : acc0;
+            } else if (sx + 1 < W) {
                 // right column = left column + 1: its tap t reads what the left column's tap t+1 reads.
                 // Taps go in batches of 8 so that the 16 LDS reads of a batch are in flight together
                 // (one wait per batch instead of one LDS round trip per tap).
@@ -680,7 +764,7 @@ __device__ __forceinline__ int reflect101_once(int p, int len)   // valid for -l
 template <int S, int K, bool EDGE>
 __global__ __launch_bounds__(EDGE ? 64 : 256) void k_level_direct(const uint8_t *__restrict__ frames, size_t frame_stride,
                                                                   int W, int H, TapsArg<K> taps, float *__restrict__ I, int w,
-                                                                  int h, int strip)
+                                                                  int h, int strip, int symm)
 {
     constexpr int R = 3 * S, r = K / 2;
     static_assert(K + 1 <= R && (K & 1), "ring of 3*S rows must hold the K+1 rows of one output");
@@ -720,6 +804,11 @@ __global__ __launch_bounds__(EDGE ? 64 : 256) void k_level_direct(const uint8_t 
         } else {
 #pragma unroll
             for (int t = 0; t <= K; t++) px[t] = (float)row[cl + t];
+        }
+        if (K == 3 && symm) {                          // SymmRowSmallFilter's order (row_small_symm)
+            o0 = px[1] * taps.k[1] + (px[0] + px[2]) * taps.k[2];
+            o1 = px[2] * taps.k[1] + (px[1] + px[3]) * taps.k[2];
+            return;
         }
         float a0 = taps.k[0] * px[0], a1 = taps.k[0] * px[1];
 #pragma unroll
@@ -895,7 +984,7 @@ bool level_direct_supported(const void *frames, int W, int H, int w, int h, int 
 
 template <int S, int K>
 static void launch_level_direct_sk(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
-                                   const float *h_kern, float *I, int w, int h)
+                                   const float *h_kern, float *I, int w, int h, int symm)
 {
     TapsArg<K> taps;
     for (int i = 0; i < K; i++) taps.k[i] = h_kern[i];
@@ -906,21 +995,21 @@ static void launch_level_direct_sk(hipStream_t s, const uint8_t *frames, size_t 
         const int nt = w - 2 > 128 ? 256 : (w - 2 > 64 ? 128 : 64);
         const int strip = 3 * best_strip_units(units, 3 * S, K + 1 - S, (int)cdivu(w - 2, nt) * nframes, 8 * (256 / nt));
         dim3 grid(cdivu(w - 2, nt), cdivu(h, strip), nframes);
-        hipLaunchKernelGGL((k_level_direct<S, K, false>), grid, dim3(nt), 0, s, frames, frame_stride, W, H, taps, I, w, h, strip);
+        hipLaunchKernelGGL((k_level_direct<S, K, false>), grid, dim3(nt), 0, s, frames, frame_stride, W, H, taps, I, w, h, strip, symm);
     }
     // border columns 0 and w-1: 32 strips of at least 12 rows per block of 64 threads
     int estrip = 3 * ((units + 31) / 32);
     if (estrip < 12) estrip = 12;
     dim3 egrid(1, cdivu((int)cdivu(h, estrip), 32), nframes);
-    hipLaunchKernelGGL((k_level_direct<S, K, true>), egrid, dim3(64), 0, s, frames, frame_stride, W, H, taps, I, w, h, estrip);
+    hipLaunchKernelGGL((k_level_direct<S, K, true>), egrid, dim3(64), 0, s, frames, frame_stride, W, H, taps, I, w, h, estrip, symm);
 }
 
 void launch_level_direct(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
-                         const float *h_kern, int ksize, float *I, int w, int h)
+                         const float *h_kern, int ksize, float *I, int w, int h, int symm)
 {
-    if (W == 2 * w && ksize == 3) launch_level_direct_sk<2, 3>(s, frames, frame_stride, W, H, nframes, h_kern, I, w, h);
-    else if (W == 4 * w && ksize == 9) launch_level_direct_sk<4, 9>(s, frames, frame_stride, W, H, nframes, h_kern, I, w, h);
-    else if (W == 8 * w && ksize == 19) launch_level_direct_sk<8, 19>(s, frames, frame_stride, W, H, nframes, h_kern, I, w, h);
+    if (W == 2 * w && ksize == 3) launch_level_direct_sk<2, 3>(s, frames, frame_stride, W, H, nframes, h_kern, I, w, h, symm);
+    else if (W == 4 * w && ksize == 9) launch_level_direct_sk<4, 9>(s, frames, frame_stride, W, H, nframes, h_kern, I, w, h, 0);
+    else if (W == 8 * w && ksize == 19) launch_level_direct_sk<8, 19>(s, frames, frame_stride, W, H, nframes, h_kern, I, w, h, 0);
 }
 
 // The fused kernel is instantiated for the window half-widths m = winsize/2 = 3..10 (winsize 6..21); other window
@@ -1064,14 +1153,14 @@ void launch_polyexp_march(hipStream_t s, const void *src, size_t src_stride, int
 }
 
 void launch_level_hpass_lds(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
-                            const float *d_kern, int ksize, const int *d_xofs, int dw, float *tmp)
+                            const float *d_kern, int ksize, const int *d_xofs, int dw, float *tmp, int symm)
 {
     const int r = ksize >> 1;
     const int ext = W + 2 * r;
     const size_t lds = sizeof(float) * (size_t)(ext + (ext >> 5) + 2 + ksize);
     dim3 grid(1, H, nframes);
     hipLaunchKernelGGL(k_level_hpass_lds, grid, dim3(256), lds, s, frames, frame_stride, W, H, d_kern, ksize, d_xofs,
-                       dw, reinterpret_cast<float2 *>(tmp));
+                       dw, reinterpret_cast<float2 *>(tmp), symm);
 }
 
 }  // namespace ofarn

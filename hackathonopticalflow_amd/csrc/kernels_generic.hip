@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void k_level_hpass(const uint8_t *__restrict__
                                                       size_t frame_stride, int W, int H,
                                                       const float *__restrict__ kern, int ksize,
                                                       const int *__restrict__ xofs, int dw,
-                                                      float2 *__restrict__ tmp)
+                                                      float2 *__restrict__ tmp, int symm)
 {
     const int dx = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
@@ -33,6 +33,18 @@ __global__ __launch_bounds__(256) void k_level_hpass(const uint8_t *__restrict__
     const int sx = xofs[dx];
     const int sx1 = sx + 1 < W ? sx + 1 : W - 1;
     float s0, s1;
+    if (symm && (ksize == 3 || ksize == 5)) {
+        // SymmRowSmallFilter<float, float> (filter.simd.hpp): centre tap first, then the symmetric pairs
+        float a[5], b[5];
+        for (int t = 0; t < ksize; t++) {
+            a[t] = (float)row[reflect101(sx - r + t, W)];
+            b[t] = (float)row[reflect101(sx1 - r + t, W)];
+        }
+        s0 = row_small_symm(a, kern, ksize);
+        s1 = row_small_symm(b, kern, ksize);
+        tmp[((size_t)blockIdx.z * H + y) * dw + dx] = make_float2(s0, s1);
+        return;
+    }
     {
         const float f = kern[0];
         s0 = f * (float)row[reflect101(sx - r, W)];
@@ -490,11 +502,11 @@ __global__ __launch_bounds__(1024) void k_grid_filter(const float2 *__restrict__
 static inline unsigned cdiv(int a, int b) { return (unsigned)((a + b - 1) / b); }
 
 void launch_level_hpass(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H,
-                        int nframes, const float *d_kern, int ksize, const int *d_xofs, int dw, float *tmp)
+                        int nframes, const float *d_kern, int ksize, const int *d_xofs, int dw, float *tmp, int symm)
 {
     dim3 grid(cdiv(dw, 256), H, nframes);
     hipLaunchKernelGGL(k_level_hpass, grid, dim3(256), 0, s, frames, frame_stride, W, H, d_kern, ksize,
-                       d_xofs, dw, reinterpret_cast<float2 *>(tmp));
+                       d_xofs, dw, reinterpret_cast<float2 *>(tmp), symm);
 }
 
 void launch_level_vpass(hipStream_t s, const float *tmp, int H, int dw, int dh, int nframes,

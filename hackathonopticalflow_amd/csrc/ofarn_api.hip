@@ -347,6 +347,7 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
     bool has_tmp[32] = {false}, hdirect[32] = {false};
     int hl_level[12] = {0};
     HLevels HL{};
+    HL.symm = c->row_small_symm;
     size_t tmp_need = 0, I_need = 0;
     bool multi = false;
     {
@@ -427,7 +428,7 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
                    level_direct_supported(d_frames, w, h, L.w, L.h, L.ksize)) {
             // exact 1/2, 1/4, 1/8 levels: row pass + column pass + resize in one kernel straight from the frames
             timed(c, s, OFARN_STAGE_LEVEL_V, k, ufr, [&] {
-                launch_level_direct(s, d_frames, fsz, w, h, nframes, L.h_kern.data(), L.ksize, ws.I, L.w, L.h);
+                launch_level_direct(s, d_frames, fsz, w, h, nframes, L.h_kern.data(), L.ksize, ws.I, L.w, L.h, c->row_small_symm);
             });
             timed(c, s, OFARN_STAGE_POLYEXP, k, ufr, [&] {
                 if (march) launch_polyexp_march(s, ws.I, npx, 0, ws.R, L.w, L.h, nframes, c->poly, L.h_kern3);
@@ -438,9 +439,9 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
             if (!tmp_of[k])
                 timed(c, s, OFARN_STAGE_LEVEL_H, k, ufr, [&] {
                     if (!c->force_generic && lds_ok)
-                        launch_level_hpass_lds(s, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, ws.tmp);
+                        launch_level_hpass_lds(s, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, ws.tmp, c->row_small_symm);
                     else
-                        launch_level_hpass(s, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, ws.tmp);
+                        launch_level_hpass(s, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, ws.tmp, c->row_small_symm);
                 });
             timed(c, s, OFARN_STAGE_LEVEL_V, k, ufr, [&] {
                 launch_level_vpass(s, tmpk, h, L.w, L.h, nframes, L.d_kern, L.ksize, L.d_xa, L.d_yofs, L.d_ya, ws.I);
@@ -645,6 +646,7 @@ int ofarn_create(const ofarn_params *params, int device, int max_w, int max_h, i
         c->force_generic = e && e[0] == '1';
     }
     if (const char *e = getenv("OFARN_DIRECT_MIN_FRAMES")) c->direct_min_frames = atoi(e);
+    if (const char *e = getenv("OFARN_ROW_LTR")) c->row_small_symm = e[0] == '1' ? 0 : 1;
     if (!poly_prepare(params->poly_n, params->poly_sigma, c->poly)) {
         delete c;
         return fail(OFARN_E_INVALID, "poly_n out of range");

@@ -226,14 +226,14 @@ int ofarn_stage_level_image(ofarn_ctx *c, const uint8_t *h_img, int w, int h, in
     HIP_TRY(hipMemcpyAsync(c->st_frames, h_img, fsz, hipMemcpyHostToDevice, c->stream));
     const bool lds_ok = (size_t)(w + 2 * (L.ksize / 2)) * 4 * 33 / 32 + 4 * (size_t)L.ksize + 64 <= 60 * 1024;
     if (!c->force_generic && level_direct_supported(c->st_frames, w, h, L.w, L.h, L.ksize))
-        launch_level_direct(c->stream, c->st_frames, fsz, w, h, 1, L.h_kern.data(), L.ksize, c->ws[0].I, L.w, L.h);
+        launch_level_direct(c->stream, c->st_frames, fsz, w, h, 1, L.h_kern.data(), L.ksize, c->ws[0].I, L.w, L.h, c->row_small_symm);
     else {
         if (!c->force_generic && level_hdirect_supported(c->st_frames, w, L.w, L.ksize))
             launch_level_hdirect(c->stream, c->st_frames, fsz, w, h, 1, L.h_kern.data(), L.ksize, c->ws[0].tmp, L.w);
         else if (!c->force_generic && lds_ok)
-            launch_level_hpass_lds(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->ws[0].tmp);
+            launch_level_hpass_lds(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->ws[0].tmp, c->row_small_symm);
         else
-            launch_level_hpass(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->ws[0].tmp);
+            launch_level_hpass(c->stream, c->st_frames, fsz, w, h, 1, L.d_kern, L.ksize, L.d_xofs, L.w, c->ws[0].tmp, c->row_small_symm);
         launch_level_vpass(c->stream, c->ws[0].tmp, h, L.w, L.h, 1, L.d_kern, L.ksize, L.d_xa, L.d_yofs, L.d_ya, c->ws[0].I);
     }
     HIP_TRY(hipMemcpyAsync(h_out, c->ws[0].I, (size_t)L.w * L.h * sizeof(float), hipMemcpyDeviceToHost, c->stream));

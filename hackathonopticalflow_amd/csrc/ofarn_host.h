@@ -115,6 +115,8 @@ struct ofarn_ctx {
     struct ProfRec { int stage, level; double units; hipEvent_t a, b; };
     bool prof_on = false;
     bool force_generic = false;   // OFARN_FORCE_GENERIC=1 or ofarn_set_option: use the unfused kernels only
+    int row_small_symm = 1;       // GaussianBlur row pass of a 3- or 5-tap kernel in SymmRowSmallFilter's order (oracle
+                                  // OFO_ROW_SMALL_SYMM); OFARN_ROW_LTR=1 when the context is created: left to right (rounds 1-2)
     int direct_min_frames = 32;   // k_level_direct marches long strips per thread: below this many frames in a wave the
                                   // row-pass + column-pass pair has more parallelism and lower latency (OFARN_DIRECT_MIN_FRAMES)
     std::vector<ProfRec> prof_pending;

@@ -36,7 +36,7 @@ struct PolyCoef {
 // Stage A: level image = resize(GaussianBlur(float(frame)))
 void launch_level_hpass(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H,
                         int nframes, const float *d_kern, int ksize, const int *d_xofs, int dw,
-                        float *tmp);
+                        float *tmp, int symm);
 void launch_level_vpass(hipStream_t s, const float *tmp, int H, int dw, int dh, int nframes,
                         const float *d_kern, int ksize, const float *d_xa, const int *d_yofs,
                         const float *d_ya, float *I);
@@ -81,8 +81,9 @@ bool polyexp_march_supported(int poly_n);
 void launch_polyexp_march(hipStream_t s, const void *src, size_t src_stride, int src_is_u8, float *R, int w, int h,
                           int nframes, const PolyCoef &c, const float *blur3);
 // Stage A pass 1 with the frame row staged in LDS (levels >= 1).
+// symm (all row passes): 1 = a kernel of 3 or 5 taps is applied in SymmRowSmallFilter's order (row_small_symm), 0 = left to right.
 void launch_level_hpass_lds(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
-                            const float *d_kern, int ksize, const int *d_xofs, int dw, float *tmp);
+                            const float *d_kern, int ksize, const int *d_xofs, int dw, float *tmp, int symm);
 // Stage A pass 1 for several levels in one launch (kernels_fast.hip): the frame row is read once.
 struct HLevel {
     const float *kern;   // device, ksize taps
@@ -93,6 +94,7 @@ struct HLevel {
 struct HLevels {
     HLevel lv[12];
     int n, rmax;
+    int symm;            // see launch_level_hpass_lds
 };
 size_t hpass_multi_lds_bytes(int W, int rmax);
 void launch_level_hpass_multi(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
@@ -101,7 +103,7 @@ void launch_level_hpass_multi(hipStream_t s, const uint8_t *frames, size_t frame
 // (kernels_fast.hip).  h_kern: host pointer to the ksize taps.
 bool level_direct_supported(const void *frames, int W, int H, int w, int h, int ksize);
 void launch_level_direct(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
-                         const float *h_kern, int ksize, float *I, int w, int h);
+                         const float *h_kern, int ksize, float *I, int w, int h, int symm);
 // Stage A row pass straight from the frames for levels whose width is exactly 1/16, 1/32 or 1/64 of the frame's
 // (kernels_fast.hip): fills the same tmp layout as the other row passes.  h_kern: host pointer to the ksize taps.
 bool level_hdirect_supported(const void *frames, int W, int w, int ksize);

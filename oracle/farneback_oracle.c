@@ -17,8 +17,9 @@
  *   modules/imgproc/src/resize.cpp          (INTER_LINEAR on CV_32F)
  * None of those files, and no cv2 wheel, exist in the build container, so this
  * file restates OpenCV's published algorithm following the
- * scalar C++ code paths statement by statement: same float/double mix, same
- * operation order, no FMA contraction (build with -ffp-contract=off).
+ * scalar C++ code paths as recalled: same float/double mix, same operation order,
+ * no FMA contraction (build with -ffp-contract=off).  Points where the recollection
+ * is uncertain are named switches below.
  *
  * PARITY UNPINNED: the reference holds no tests, golden vectors or fixtures for
  * this path and OpenCV cannot be run here.  What pins this file instead are
@@ -53,6 +54,18 @@
 #define OFO_DET_EPS 1e-3             /* idet = 1/(g11*g22 - g12*g12 + 1e-3)          */
 #define OFO_BORDER 5
 static const float ofo_border_tab[OFO_BORDER] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+
+/* GaussianBlur row pass of a SMALL symmetric float kernel.  filter.simd.hpp getLinearRowFilter() hands a symmetrical
+ * CV_32F kernel with ksize <= 5 to SymmRowSmallFilter<float, float>, whose arithmetic is
+ *     ksize 3:  D = S[0]*k0 + (S[-1] + S[1])*k1
+ *     ksize 5:  D = S[0]*k0 + (S[-1] + S[1])*k1 + (S[-2] + S[2])*k2          (k0 = centre tap)
+ * not the left-to-right sum of the general RowFilter used for wider kernels.  1 = that order (default since round 3),
+ * 0 = plain left to right for every size (rounds 1-2).  Level 0 ([1/4, 1/2, 1/4] on byte values) is exact either way;
+ * a level with sigma = 0.5 (ksize 3) or a ksize-5 level rounds differently.  Run-time switch: ofo_set_row_small_symm().
+ * (Real wheels may differ further in the last bit: the AVX2 dispatch of these filters uses v_muladd = FMA, and builds
+ * with IPP route GaussianBlur through ippiFilterGaussian.  Neither is restated: parity is unpinned, see above.) */
+#define OFO_ROW_SMALL_SYMM 1
+static int ofo_row_small_symm = OFO_ROW_SMALL_SYMM;
 
 #define OFO_BOX_RUNNING 0   /* OpenCV's literal order: double running sums, float row differences */
 #define OFO_BOX_DIRECT  1   /* same window, each sum taken directly in a fixed order                */
@@ -145,9 +158,12 @@ OFO_API int ofo_gaussian_kernel(int n, double sigma, float *out)
     return 0;
 }
 
+OFO_API void ofo_set_row_small_symm(int on) { ofo_row_small_symm = on != 0; }
+OFO_API int ofo_get_row_small_symm(void) { return ofo_row_small_symm; }
+
 /* Separable filter on float32, BORDER_REFLECT_101, row pass then column pass.
  * Order of operations per output sample (OpenCV's scalar filter engine):
- *   row    : s = kx[0]*S[0]; s += kx[k]*S[k]            (k = 1..n-1, left to right)
+ *   row    : s = kx[0]*S[0]; s += kx[k]*S[k]            (k = 1..n-1, left to right; ksize <= 5: OFO_ROW_SMALL_SYMM above)
  *   column : s = ky[r]*S[0]; s += ky[r+k]*(S[+k]+S[-k]) (k = 1..r, centre outwards)
  */
 OFO_API void ofo_gaussian_blur(const float *src, int W, int H, int ksize, double sigma, float *dst)
@@ -163,6 +179,19 @@ OFO_API void ofo_gaussian_blur(const float *src, int W, int H, int ksize, double
         const float *s = src + (size_t)y * W;
         float *t = tmp + (size_t)y * W;
         for (int x = 0; x < W + 2 * r; x++) ext[x] = s[xi[x]];
+        if (ofo_row_small_symm && ksize == 3) {          /* SymmRowSmallFilter, symmetrical, ksize == 3 */
+            const float k0 = kx[r], k1 = kx[r + 1];
+            for (int x = 0; x < W; x++) { const float *S = ext + x + r; t[x] = S[0] * k0 + (S[-1] + S[1]) * k1; }
+            continue;
+        }
+        if (ofo_row_small_symm && ksize == 5) {          /* ksize == 5 */
+            const float k0 = kx[r], k1 = kx[r + 1], k2 = kx[r + 2];
+            for (int x = 0; x < W; x++) {
+                const float *S = ext + x + r;
+                t[x] = S[0] * k0 + (S[-1] + S[1]) * k1 + (S[-2] + S[2]) * k2;
+            }
+            continue;
+        }
         for (int x = 0; x < W; x++) t[x] = kx[0] * ext[x];
         for (int k = 1; k < ksize; k++) {
             const float f = kx[k];

@@ -89,6 +89,9 @@ def lib(omp: bool = False) -> C.CDLL:
                                           C.POINTER(OfoParams), C.c_int, fp, C.c_int]
         l.ofo_farneback_batch.restype = C.c_int
         l.ofo_max_threads.restype = C.c_int
+        l.ofo_set_row_small_symm.argtypes = [C.c_int]
+        l.ofo_set_row_small_symm.restype = None
+        l.ofo_get_row_small_symm.restype = C.c_int
         l.ofo_grid_points.argtypes = [C.c_int, C.c_int, C.c_int, fp]
         l.ofo_grid_points.restype = C.c_int
         l.ofo_vector_filter.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, u8p, fp,
@@ -131,6 +134,16 @@ def _u8p(a):
 def _params(pyr_scale=0.5, levels=3, winsize=15, iterations=3, poly_n=5, poly_sigma=1.2, flags=0):
     return OfoParams(float(pyr_scale), int(levels), int(winsize), int(iterations), int(poly_n),
                      float(poly_sigma), int(flags))
+
+
+def set_row_small_symm(on: bool) -> bool:
+    """OFO_ROW_SMALL_SYMM switch of farneback_oracle.c (both builds of the library): True (default) = the GaussianBlur row
+    pass of a ksize <= 5 kernel in SymmRowSmallFilter's order, False = plain left to right (rounds 1-2).  Returns the
+    previous setting."""
+    prev = bool(lib().ofo_get_row_small_symm())
+    for omp in (False, True):
+        lib(omp).ofo_set_row_small_symm(int(bool(on)))
+    return prev
 
 
 # --------------------------------------------------------------------------- geometry

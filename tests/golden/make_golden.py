@@ -6,6 +6,7 @@ The reference ships no fixtures for its Farneback path and cv2 cannot be importe
 8c), so these vectors are outputs of the repo's own oracle, PARITY UNPINNED against real OpenCV.
 They pin (a) the oracle against accidental change and (b) the HIP path on the GPU box, where they
 are compared bit for bit (flow_direct: the device summation order) and within tolerance (flow_running = OpenCV's literal order).
+flow_direct_row_ltr: flow_direct with the oracle's OFO_ROW_SMALL_SYMM switch off (the order of rounds 1-2, still selectable on both sides).
 """
 import os
 import sys
@@ -38,8 +39,14 @@ def main():
         fd = O.farneback(prev, nxt, box_mode=O.BOX_BLOCKED, **kw)
         fr = O.farneback(prev, nxt, box_mode=O.BOX_RUNNING, **kw)
         mask, v = O.danger_map_numpy(fd, w, h, 30)
+        # the same with the row pass of 3- and 5-tap Gaussian kernels left to right (OFO_ROW_SMALL_SYMM = 0, the rounds 1-2 order)
+        O.set_row_small_symm(False)
+        try:
+            fl = O.farneback(prev, nxt, box_mode=O.BOX_BLOCKED, **kw)
+        finally:
+            O.set_row_small_symm(True)
         np.savez_compressed(os.path.join(out, name + ".npz"), prev=prev, next=nxt, shift=np.int64(shift),
-                            flow_direct=fd, flow_running=fr, mask=mask, v=v,
+                            flow_direct=fd, flow_running=fr, flow_direct_row_ltr=fl, mask=mask, v=v,
                             params=np.array(repr(sorted(kw.items()))))
         print(name, fd.shape, "max |direct-running| =", float(np.abs(fd - fr).max()), "kept", int(mask.sum()))
 

@@ -244,6 +244,47 @@ def test_golden_fixtures(H, iter_kernel, path):
     np.testing.assert_array_equal(v, g["v"])
 
 
+def test_row_order_of_small_gaussian_kernels(H, oracle, monkeypatch):
+    """GaussianBlur's row pass of a 3- or 5-tap kernel runs in SymmRowSmallFilter's order, S[0]*k0 + (S[-1]+S[1])*k1 (+ ...), on
+    both sides by default (oracle OFO_ROW_SMALL_SYMM; every row-pass kernel: generic, LDS, multi-level, direct 1/2).  Level
+    images with ksize 3 (pyr_scale 0.5, level 1) and ksize 5 (pyr_scale 0.6, level 2) are bit-exact on every path, the plain
+    left-to-right order of rounds 1-2 is still selectable on both sides (OFARN_ROW_LTR=1 when the context is created /
+    oracle.set_row_small_symm(False)) and reproduces the goldens' flow_direct_row_ltr."""
+    img, _, _ = translated_pair(240, 320, 9)
+    for env in ({}, {"OFARN_FORCE_GENERIC": "1"}, {"OFARN_DIRECT_MIN_FRAMES": "1"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        for ps, lv in ((0.5, 2), (0.6, 3)):
+            with H.FarnebackEngine(320, 240, 1, levels=lv, pyr_scale=ps) as eng:
+                ks_seen = set()
+                for k, (lw, lh, ks, sg) in enumerate(H.level_plan(320, 240, levels=lv, pyr_scale=ps)):
+                    ks_seen.add(ks)
+                    np.testing.assert_array_equal(eng.stage_level_image(img, k), oracle.level_image(img, ks, sg, lw, lh),
+                                                  err_msg=f"{env} pyr_scale {ps} level {k} ksize {ks}")
+                assert 3 in ks_seen and (ps == 0.5 or 5 in ks_seen)
+            a, b, _ = translated_pair(240, 320, 10, max_shift=3)
+            with H.FarnebackEngine(320, 240, 1, levels=lv, pyr_scale=ps) as eng:
+                np.testing.assert_array_equal(eng.calc(a, b), oracle.farneback(a, b, levels=lv, pyr_scale=ps, box_mode=oracle.BOX_BLOCKED))
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    monkeypatch.setenv("OFARN_ROW_LTR", "1")
+    oracle.set_row_small_symm(False)
+    try:
+        for path in GOLDEN:
+            g = np.load(path, allow_pickle=False)
+            kw = dict(ast.literal_eval(str(g["params"])))
+            hh, ww = g["prev"].shape
+            with H.FarnebackEngine(ww, hh, 1, **kw) as eng:
+                got = eng.calc(g["prev"], g["next"])
+            np.testing.assert_array_equal(got, g["flow_direct_row_ltr"])
+            assert not np.array_equal(got, g["flow_direct"]) or kw.get("levels", 3) == 0
+        with H.FarnebackEngine(320, 240, 1, levels=2) as eng:
+            for k, (lw, lh, ks, sg) in enumerate(H.level_plan(320, 240, levels=2)):
+                np.testing.assert_array_equal(eng.stage_level_image(img, k), oracle.level_image(img, ks, sg, lw, lh))
+    finally:
+        oracle.set_row_small_symm(True)
+
+
 @pytest.mark.parametrize("w,h,kw", [(320, 240, dict(levels=2)), (333, 251, dict(levels=1, winsize=9, iterations=2)),
                                     (200, 160, dict(levels=0, winsize=20)),
                                     # the fused Gaussian iteration kernel: every instantiation (m = 3..8), multi-strip heights,
@@ -898,7 +939,7 @@ def test_trig_outputs_vs_literal_numpy(H, oracle):
     """V, the integer vectors and the hue on >= 10^6 random vectors: equal to the NumPy lines with correctly rounded
     arctan2 / cos / sin (the contract), and within a measured rate of the LITERAL lines on this machine's NumPy, whose
     float32 arctan2 is a SIMD approximation (<= 3.2 ulp here, 0.5 / 3.5 mismatches per 10^6 after truncation measured in
-    the build container; the GPU box has another CPU, so the bound is generous: 50 per 10^6)."""
+    the build container, 0 and 1 on the GPU box; the bound is 5 per 10^6 for both)."""
     rng = np.random.default_rng(42)
     w, h, step = 1920, 1080, 5                      # 82 944 grid points per map (also: P far beyond one LDS sort)
     pts = oracle.grid_points_numpy(w, h, step)
@@ -916,14 +957,14 @@ def test_trig_outputs_vs_literal_numpy(H, oracle):
         bad_np += int((iflow[i] != if_np).any(axis=1).sum())
     print(f"integer vectors: {bad_cr} differ from correctly rounded NumPy, {bad_np} from literal NumPy, of {n_maps * P}")
     assert bad_cr == 0
-    assert bad_np <= 50 * n_maps * P // 1_000_000
+    assert bad_np <= 5 * n_maps * P // 1_000_000
     flow = vec[:12].reshape(864, 1152, 2)           # 10^6 pixels through draw_hsv
     with H.FarnebackEngine(1152, 864, 1) as eng:
         _, hsv = eng.flow_hsv(flow, return_hsv=True)
     np.testing.assert_array_equal(hsv, oracle.draw_hsv_planes_numpy(flow, cr=True))
     bad_h = int((hsv[..., 0] != oracle.draw_hsv_planes_numpy(flow, cr=False)[..., 0]).sum())
     print(f"hue: {bad_h} of {flow.shape[0] * flow.shape[1]} differ from literal NumPy")
-    assert bad_h <= 100 * flow.shape[0] * flow.shape[1] // 1_000_000
+    assert bad_h <= 5 * flow.shape[0] * flow.shape[1] // 1_000_000
 
 
 def test_fine_grid_and_nan(H, oracle):
@@ -1003,6 +1044,36 @@ def test_bench_two_gloo_ranks_share_the_gpu():
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["global_pairs"] == 16
     assert out["config"]["pairs_per_gpu"] == 8 and out["value"] > 0
     assert out["gathered_danger_maps_checked"] is True
+
+
+@pytest.mark.parametrize("config,batch", [(4, 16), (5, 2)])
+def test_bench_rccl_leg_at_world_size_one(config, batch):
+    """The RCCL leg of BASELINE configs 4 and 5 as far as ONE GPU allows: `bench.py --gpus 1 --backend nccl --force-dist` starts
+    its rank as a fresh child through torch.distributed.run, initialises the `nccl` (= RCCL) process group at world size 1 and
+    runs the allocation-free all_gather_into_tensor of the danger maps on DEVICE tensors inside the timed region; afterwards the
+    rank checks its shard at its place in the gathered arrays.  (Two nccl ranks on one GPU are not possible; the 2-rank
+    layout is covered by the gloo rehearsal above and by tests/test_distributed_cpu.py.)  The log is kept under gpurun_out/."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--backend", "nccl", "--force-dist", "--config", str(config),
+           "--batch", str(batch), "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--no-family-check"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", f"bench_rccl_ws1_config{config}.log"), "w") as f:
+        f.write("$ " + " ".join(cmd) + "\n" + r.stdout + "\n---- stderr ----\n" + r.stderr[-4000:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["ranks"] == 1 and out["scaling"] == "strong" and out["config"]["global_pairs"] == batch
+    assert out["gathered_danger_maps_checked"] is True
+    assert out["collective"]["backend"] == "nccl" and out["collective"]["device"].startswith("cuda")
+    assert out["collective"]["calls"] >= 3 and out["value"] > 0
+    assert out["roofline"]["frac"] <= 1.0
 
 
 def test_workspace_grows_on_demand_and_fails_cleanly(H, oracle, monkeypatch):

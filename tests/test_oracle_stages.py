@@ -366,6 +366,72 @@ def test_golden_fixtures_pin_the_oracle(oracle):
         np.testing.assert_array_equal(v, g["v"])
 
 
+def test_row_small_symm_switch(oracle):
+    """OFO_ROW_SMALL_SYMM (OpenCV's SymmRowSmallFilter order for 3- and 5-tap Gaussian rows, the default) against the plain
+    left-to-right order of rounds 1-2: identical where the arithmetic is exact (level 0: [1/4, 1/2, 1/4] on byte values, and any
+    kernel wider than 5 taps, which never takes that filter), different in the last bits at a sigma = 0.5 level (ksize 3) and at
+    a ksize-5 level; both match a direct NumPy float32 restatement of their formula; the old order stays selectable and is
+    what the goldens' flow_direct_row_ltr holds."""
+    import glob
+    import os
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (70, 90)).astype(np.uint8)
+    f = img.astype(np.float32)
+
+    def numpy_rows(ksize, sigma, symm):
+        k = oracle.gaussian_kernel(ksize, sigma)
+        r = ksize // 2
+        e = np.pad(f, ((0, 0), (r, r)), mode="reflect")
+        S = lambda o: e[:, r + o:r + o + f.shape[1]]
+        if symm and ksize == 3:
+            return S(0) * k[1] + (S(-1) + S(1)) * k[2]
+        if symm and ksize == 5:
+            return S(0) * k[2] + (S(-1) + S(1)) * k[3] + (S(-2) + S(2)) * k[4]
+        t = k[0] * S(-r)
+        for i in range(1, ksize):
+            t = t + k[i] * S(i - r)
+        return t
+
+    try:
+        for ksize, sigma, differs in ((3, 0.0, False), (3, 0.5, True), (5, 0.9, True), (9, 1.5, False)):
+            oracle.set_row_small_symm(True)
+            a = oracle.gaussian_blur(f, ksize, sigma)
+            oracle.set_row_small_symm(False)
+            b = oracle.gaussian_blur(f, ksize, sigma)
+            assert (not np.array_equal(a, b)) == differs, (ksize, sigma)
+            if differs:
+                assert np.abs(a - b).max() <= 2 ** -15 * 4        # an ulp or two of values < 256
+            # the row pass itself against NumPy float32, both orders: feed a column-constant image so that the column pass
+            # sees identical rows (k[r]*t + k[r+i]*(t + t) is then the same function of t for both settings)
+            for symm in (True, False):
+                oracle.set_row_small_symm(symm)
+                rows = numpy_rows(ksize, sigma, symm).astype(np.float32)
+                one = np.repeat(f[:1], 8, axis=0)
+                got = oracle.gaussian_blur(one, ksize, sigma)
+                k = oracle.gaussian_kernel(ksize, sigma)
+                r = ksize // 2
+                t = rows[:1]
+                want = k[r] * t
+                for i in range(1, r + 1):
+                    want = want + k[r + i] * (t + t)
+                np.testing.assert_array_equal(got[3:4], want.astype(np.float32))
+        # whole pipeline: level 0 alone is exact either way; with a sigma = 0.5 level the flows differ by ~1e-6 px
+        p, n, _ = translated_pair(96, 128, 31)
+        oracle.set_row_small_symm(True)
+        f0s, f1s = oracle.farneback(p, n, levels=0), oracle.farneback(p, n, levels=1)
+        oracle.set_row_small_symm(False)
+        f0l, f1l = oracle.farneback(p, n, levels=0), oracle.farneback(p, n, levels=1)
+        np.testing.assert_array_equal(f0s, f0l)
+        assert not np.array_equal(f1s, f1l) and np.abs(f1s - f1l).max() < 1e-4
+        for path in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))):
+            g = np.load(path, allow_pickle=False)
+            kw = dict(eval(str(g["params"])))
+            np.testing.assert_array_equal(oracle.farneback(g["prev"], g["next"], box_mode=oracle.BOX_BLOCKED, **kw),
+                                          g["flow_direct_row_ltr"])
+    finally:
+        oracle.set_row_small_symm(True)
+
+
 def test_rejects_bad_arguments(oracle):
     p, n, _ = translated_pair(64, 64, 1)
     with pytest.raises(ValueError):
