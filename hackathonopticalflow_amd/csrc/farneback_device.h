@@ -53,6 +53,16 @@ __device__ __forceinline__ void store_r(float *__restrict__ Rf, size_t npx, unsi
     *reinterpret_cast<float *>(reinterpret_cast<char *>(Rf + 4 * npx) + o * 4u) = v[4];
 }
 
+// The two frames of pair p in an R buffer: R0 = frame p * |fstep|, R1 = the frame behind it (fstep > 0: batches; 1 = video
+// order, 2 = independent pairs) or in FRONT of it (fstep < 0: the streaming session keeps two slots per level and writes the
+// newest frame into the slot the older one does not occupy, so every other turn the later frame sits in the lower slot).
+__device__ __forceinline__ void pair_frames(const float *R, int fstep, size_t p, size_t npx, const float *&R0, const float *&R1)
+{
+    const size_t st = r_frame_stride(npx);
+    R0 = R + p * (size_t)(fstep < 0 ? -fstep : fstep) * st;
+    R1 = fstep < 0 ? R0 - st : R0 + st;
+}
+
 // FarnebackUpdateMatrices for one pixel (optflowgf.cpp), all float32, no FMA contraction.
 // R0, R1: the pair's two frames in the 4+1 layout; (dx, dy) the current flow at (x, y).
 __device__ __forceinline__ void update_matrices_px(const float *__restrict__ R0, const float *__restrict__ R1,

@@ -112,8 +112,8 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
     const int y1 = min(y0 + strip_h, h);
     const size_t npx = (size_t)w * h;
     const size_t p = bidz;
-    const float *R0 = R + p * fstep * r_frame_stride(npx);
-    const float *R1 = R0 + r_frame_stride(npx);
+    const float *R0, *R1;
+    pair_frames(R, fstep, p, npx, R0, R1);
     const float2 *fin = MODE == 2 ? flow_in + p * npx : nullptr;
     float2 *fout = flow_out + p * npx;
 
@@ -1023,7 +1023,7 @@ bool flow_iter_supported(int winsize)
 template <int M_>
 static void launch_flow_iter_m(hipStream_t s, const float *R, int fstep, const float *flow_in, float *flow_out, int w,
                                int h, int npairs, int winsize, int mode, const float *coarse, int cw, int ch,
-                               const int *d_xofs, const float *d_xa, const int *d_yofs, const float *d_ya, float mul)
+                               const int *d_xofs, const float *d_xa, const int *d_yofs, const float *d_ya, float mul, int tile_mode)
 {
     constexpr int OUTW = march_out_width(M_);
     constexpr int B = 2 * M_ + 1;
@@ -1034,7 +1034,7 @@ static void launch_flow_iter_m(hipStream_t s, const float *R, int fstep, const f
     dim3 grid(cdivu(w, OUTW), cdivu(h, strip_h), npairs);
     // a grid that leaves most CUs without a block is latency bound: the tile kernel (kernels_tile.hip) does the same arithmetic
     // with all of a tile's gathers in flight at once
-    if (flow_iter_tile_supported(winsize) && flow_iter_tile_preferred((long)grid.x * grid.y * grid.z)) {
+    if (flow_iter_tile_supported(winsize) && flow_iter_tile_preferred((long)grid.x * grid.y * grid.z, tile_mode)) {
         launch_flow_iter_tile(s, R, fstep, flow_in, flow_out, w, h, npairs, winsize, mode, coarse, cw, ch, d_xofs, d_xa, mul);
         return;
     }
@@ -1073,12 +1073,12 @@ static void launch_flow_iter_m(hipStream_t s, const float *R, int fstep, const f
 // mode 0: zero input flow; 1: upsample from coarse (up_* valid); 2: read flow_in.
 void launch_flow_iter(hipStream_t s, const float *R, int fstep, const float *flow_in, float *flow_out, int w,
                       int h, int npairs, int winsize, int mode, const float *coarse, int cw, int ch,
-                      const int *d_xofs, const float *d_xa, const int *d_yofs, const float *d_ya, float mul)
+                      const int *d_xofs, const float *d_xa, const int *d_yofs, const float *d_ya, float mul, int tile_mode)
 {
 #define OFARN_FI_CASE(M)                                                                                          \
     case M:                                                                                                       \
         launch_flow_iter_m<M>(s, R, fstep, flow_in, flow_out, w, h, npairs, winsize, mode, coarse, cw, ch, d_xofs, \
-                              d_xa, d_yofs, d_ya, mul);                                                            \
+                              d_xa, d_yofs, d_ya, mul, tile_mode);                                                 \
         break;
     switch (winsize / 2) {
         OFARN_FI_CASE(3) OFARN_FI_CASE(4) OFARN_FI_CASE(5) OFARN_FI_CASE(6) OFARN_FI_CASE(7) OFARN_FI_CASE(8) OFARN_FI_CASE(9)

@@ -51,8 +51,8 @@ __global__ __launch_bounds__(FI_THREADS, OFARN_GAUSS_WAVES) void k_flow_iter_gau
     const int y1 = min(y0 + strip_h, h);
     const size_t npx = (size_t)w * h;
     const size_t p = bidz;
-    const float *R0 = R + p * fstep * r_frame_stride(npx);
-    const float *R1 = R0 + r_frame_stride(npx);
+    const float *R0, *R1;
+    pair_frames(R, fstep, p, npx, R0, R1);
     const float2 *fin = MODE == 2 ? flow_in + p * npx : nullptr;
     float2 *fout = flow_out + p * npx;
 

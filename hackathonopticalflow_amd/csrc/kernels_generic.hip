@@ -207,8 +207,8 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
     if (x >= w) return;
     const size_t npx = (size_t)w * h;
     const size_t p = blockIdx.z;
-    const float *R0 = R + p * fstep * r_frame_stride(npx);
-    const float *R1 = R0 + r_frame_stride(npx);
+    const float *R0, *R1;
+    pair_frames(R, fstep, p, npx, R0, R1);
     const float2 d = flow[p * npx + (size_t)y * w + x];
     float m[5];
     update_matrices_px(R0, R1, npx, w, h, x, y, d.x, d.y, m);

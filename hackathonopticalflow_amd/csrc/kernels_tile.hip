@@ -33,8 +33,8 @@ __global__ __launch_bounds__(256) void k_flow_iter_tile(const float *__restrict_
     const int x0 = blockIdx.x * TI_TW, yb = blockIdx.y * B;
     const size_t npx = (size_t)w * h;
     const size_t p = blockIdx.z;
-    const float *R0 = R + p * fstep * r_frame_stride(npx);
-    const float *R1 = R0 + r_frame_stride(npx);
+    const float *R0, *R1;
+    pair_frames(R, fstep, p, npx, R0, R1);
     const float2 *fin = MODE == 2 ? flow_in + p * npx : nullptr;
     const float2 *coarse = MODE == 1 ? up.coarse + p * (size_t)up.cw * up.ch : nullptr;
 
@@ -123,10 +123,11 @@ bool flow_iter_tile_supported(int winsize)
 }
 
 // The marching kernel wins as soon as its blocks fill the chip; below that a launch is latency bound and the tile kernel wins.
-// `marching_blocks`: the grid the marching kernel would be launched with.  OFARN_TILE=0 / 1 forces the choice (tests, A/B runs).
-bool flow_iter_tile_preferred(long marching_blocks)
+// `marching_blocks`: the grid the marching kernel would be launched with.  tile_mode 0 / 1 forces the choice (the context's
+// "tile" option: OFARN_TILE when the context is created, or ofarn_set_option; tests, A/B runs), -1 = by grid size.
+bool flow_iter_tile_preferred(long marching_blocks, int tile_mode)
 {
-    if (const char *e = getenv("OFARN_TILE")) return e[0] != '0';      // read per call: the tests switch it between cases
+    if (tile_mode >= 0) return tile_mode != 0;
     return marching_blocks <= (long)march_cu_count();
 }
 

@@ -324,14 +324,68 @@ hipEvent_t prof_event(ofarn_ctx *c)
 }
 
 
+// Which kernel builds each level image of a wave and what the row-pass intermediates need (offsets only; nothing is launched).
+struct WavePlan {
+    size_t tmp_off[32] = {0};
+    bool has_tmp[32] = {false}, hdirect[32] = {false};
+    int hl_level[12] = {0};
+    HLevels HL{};
+    size_t tmp_need = 0, I_need = 0;     // floats
+    bool multi = false;
+};
+
+void plan_wave(const ofarn_ctx *c, const uint8_t *d_frames, int nframes, int w, int h, WavePlan &p)
+{
+    const int nlev = (int)c->lv.size() - 1;
+    const bool march0 = !c->force_generic && polyexp_march_supported(c->prm.poly_n);
+    p.HL.symm = c->row_small_symm;
+    size_t off = 0, single = 0;
+    bool ok = !c->force_generic;
+    for (int k = nlev; k >= 0; k--) {
+        const Level &L = c->lv[k];
+        if (march0 && L.w == w && L.h == h && L.ksize == 3) continue;   // fused into the poly expansion, no level image
+        p.I_need = std::max(p.I_need, (size_t)nframes * L.w * L.h);
+        if (!c->force_generic && nframes >= c->direct_min_frames && level_direct_supported(d_frames, w, h, L.w, L.h, L.ksize))
+            continue;   // built by k_level_direct, no tmp
+        const size_t need = (size_t)nframes * h * L.w * 2;
+        single = std::max(single, need);
+        if (!ok) continue;
+        if (nframes >= c->direct_min_frames && level_hdirect_supported(d_frames, w, L.w, L.ksize))
+            p.hdirect[k] = true;   // 1/16, 1/32, 1/64 widths: row pass straight from the frames, no LDS staging
+        else if (p.HL.n >= 12) { ok = false; continue; }
+        else {
+            p.hl_level[p.HL.n] = k;
+            p.HL.lv[p.HL.n++] = HLevel{L.d_kern, L.d_xofs, nullptr, L.w, L.ksize};
+            if (L.ksize / 2 > p.HL.rmax) p.HL.rmax = L.ksize / 2;
+        }
+        p.has_tmp[k] = true;
+        p.tmp_off[k] = off;
+        off += need;
+    }
+    p.HL.rmax = (p.HL.rmax + 3) & ~3;   // border width in LDS: a multiple of 4 keeps the 16-byte staging writes aligned
+    p.multi = ok && (p.HL.n == 0 || hpass_multi_lds_bytes(w, p.HL.rmax) <= 60 * 1024);
+    p.tmp_need = p.multi ? off : single;
+}
+
 // One wave: npairs <= max_batch pairs, frames already in HBM.
 // d_init (OPTFLOW_USE_INITIAL_FLOW): full-resolution start flows float[npairs][h][w][2]; may alias d_flow.
 int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, int pairs_mode, int w,
-             int h, float *d_flow, uint8_t *d_mask, uint8_t *d_v, int wi = 0, const float *d_init = nullptr)
+             int h, float *d_flow, uint8_t *d_mask, uint8_t *d_v, int wi, const float *d_init, ofarn_ctx::Stream *st)
 {
     ofarn_ctx::Workspace &ws = c->ws[wi];
-    const int fstep = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? 1 : 2;
-    const int nframes = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? npairs + 1 : 2 * npairs;
+    // streaming turn: one new frame into slot `snew`; the pair is (slot cur, slot snew), one pair
+    const int snew = st ? (st->have ? st->cur ^ 1 : 0) : 0;
+    const bool iterate = !st || st->have;
+    if (st) npairs = 1;
+    const int fstep = st ? (snew > st->cur ? 1 : -1) : (pairs_mode == OFARN_PAIRS_CONSECUTIVE ? 1 : 2);
+    const int nframes = st ? 1 : (pairs_mode == OFARN_PAIRS_CONSECUTIVE ? npairs + 1 : 2 * npairs);
+    // where level k's polynomial expansions are written (stages A + B) and read (iterations)
+    auto R_ab = [&](int k) -> float * {
+        return st ? st->R + st->off[k] + (size_t)snew * r_frame_stride((size_t)c->lv[k].w * c->lv[k].h) : ws.R;
+    };
+    auto R_it = [&](int k) -> const float * {
+        return st ? st->R + st->off[k] + (size_t)st->cur * r_frame_stride((size_t)c->lv[k].w * c->lv[k].h) : ws.R;
+    };
     const size_t fsz = (size_t)w * h;
     const int nlev = (int)c->lv.size() - 1;
     float *prev = nullptr;
@@ -341,67 +395,54 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
                        (gauss ? flow_iter_gauss_supported(c->prm.winsize) : flow_iter_supported(c->prm.winsize));
     // Row pass of the level build for all levels that need one, in a single launch; tmp_of[k] is where level k's
     // rows go.  The plan is made first (offsets only), then the workspace is grown to what it needs.
-    const bool march0 = !c->force_generic && polyexp_march_supported(c->prm.poly_n);
+    WavePlan wp;
+    plan_wave(c, d_frames, nframes, w, h, wp);
     float *tmp_of[32] = {nullptr};
-    size_t tmp_off[32] = {0};
-    bool has_tmp[32] = {false}, hdirect[32] = {false};
-    int hl_level[12] = {0};
-    HLevels HL{};
-    HL.symm = c->row_small_symm;
-    size_t tmp_need = 0, I_need = 0;
-    bool multi = false;
+    const bool (&has_tmp)[32] = wp.has_tmp;
+    const bool (&hdirect)[32] = wp.hdirect;
+    HLevels &HL = wp.HL;
+    const bool multi = wp.multi;
     {
-        size_t off = 0, single = 0;
-        bool ok = !c->force_generic;
-        for (int k = nlev; k >= 0; k--) {
-            const Level &L = c->lv[k];
-            if (march0 && L.w == w && L.h == h && L.ksize == 3) continue;   // fused into the poly expansion, no level image
-            I_need = std::max(I_need, (size_t)nframes * L.w * L.h);
-            if (!c->force_generic && nframes >= c->direct_min_frames && level_direct_supported(d_frames, w, h, L.w, L.h, L.ksize))
-                continue;   // built by k_level_direct, no tmp
-            const size_t need = (size_t)nframes * h * L.w * 2;
-            single = std::max(single, need);
-            if (!ok) continue;
-            if (nframes >= c->direct_min_frames && level_hdirect_supported(d_frames, w, L.w, L.ksize))
-                hdirect[k] = true;   // 1/16, 1/32, 1/64 widths: row pass straight from the frames, no LDS staging
-            else if (HL.n >= 12) { ok = false; continue; }
-            else {
-                hl_level[HL.n] = k;
-                HL.lv[HL.n++] = HLevel{L.d_kern, L.d_xofs, nullptr, L.w, L.ksize};
-                if (L.ksize / 2 > HL.rmax) HL.rmax = L.ksize / 2;
-            }
-            has_tmp[k] = true;
-            tmp_off[k] = off;
-            off += need;
-        }
-        HL.rmax = (HL.rmax + 3) & ~3;   // border width in LDS: a multiple of 4 keeps the 16-byte staging writes aligned
-        multi = ok && (HL.n == 0 || hpass_multi_lds_bytes(w, HL.rmax) <= 60 * 1024);
-        tmp_need = multi ? off : single;
-    }
-    {
-        const size_t M_need = fused ? 0 : (size_t)npairs * fsz * 5;   // the fused iteration kernel keeps M on chip
-        int rc = ws_reserve(c, wi, tmp_need, I_need, 0, M_need, 0);
+        const size_t M_need = (fused || !iterate) ? 0 : (size_t)npairs * fsz * 5;   // the fused iteration kernel keeps M on chip
+        int rc = ws_reserve(c, wi, wp.tmp_need, wp.I_need, 0, M_need, 0, stream_is_capturing(s));
         if (rc) return rc;
     }
+    if (c->debug_fail_wave >= 0 && c->debug_fail_wave-- == 0)      // test hook (ofarn_set_option "debug_fail_wave")
+        return fail(OFARN_E_NOMEM, "injected failure (debug_fail_wave)");
+    // Streaming turn, latency mode: the new frame's level images and polynomial expansions (12 small launches) do not depend on
+    // the iterations of the coarser levels, only the other way round.  They go to an internal stream in level order, an event
+    // behind each level's expansion; the caller's stream runs the iteration chain and waits for a level's event just before
+    // that level's first iteration.  The critical path is then stages A + B of the COARSEST level + the iterations, not all of
+    // A + B.  Possible here because every level has its own R slots (a batch wave reuses one R buffer level after level);
+    // ws.tmp / ws.I are only touched by the A + B chain, which stays on one stream.  Per-kernel timing keeps one stream.
+    const bool overlap = st && iterate && !c->prof_on && c->stream_overlap && c->aux[0] && c->ev_fork;
+    hipStream_t sab = overlap ? c->aux[0] : s;
+    if (overlap) {
+        for (int k = 0; k <= nlev; k++)
+            if (!c->ev_level[k] && hipEventCreateWithFlags(&c->ev_level[k], hipEventDisableTiming) != hipSuccess)
+                return fail(OFARN_E_HIP, "event creation failed");
+        HIP_TRY(hipEventRecord(c->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(sab, c->ev_fork, 0));
+    }
     if (multi) {
-        for (int k = 0; k <= nlev; k++) if (has_tmp[k]) tmp_of[k] = ws.tmp + tmp_off[k];
-        for (int i = 0; i < HL.n; i++) HL.lv[i].dst = tmp_of[hl_level[i]];
+        for (int k = 0; k <= nlev; k++) if (has_tmp[k]) tmp_of[k] = ws.tmp + wp.tmp_off[k];
+        for (int i = 0; i < HL.n; i++) HL.lv[i].dst = tmp_of[wp.hl_level[i]];
         if (HL.n > 0) {
             double units = 0;
             for (int i = 0; i < HL.n; i++) units += (double)HL.lv[i].dw * h * nframes;
-            timed(c, s, OFARN_STAGE_LEVEL_H, 31, units, [&] { launch_level_hpass_multi(s, d_frames, fsz, w, h, nframes, HL); });
+            timed(c, sab, OFARN_STAGE_LEVEL_H, 31, units, [&] { launch_level_hpass_multi(sab, d_frames, fsz, w, h, nframes, HL); });
         }
         for (int k = nlev; k >= 0; k--)
             if (hdirect[k]) {
                 const Level &L = c->lv[k];
-                timed(c, s, OFARN_STAGE_LEVEL_H, k, (double)L.w * h * nframes, [&] {
-                    launch_level_hdirect(s, d_frames, fsz, w, h, nframes, L.h_kern.data(), L.ksize, tmp_of[k], L.w);
+                timed(c, sab, OFARN_STAGE_LEVEL_H, k, (double)L.w * h * nframes, [&] {
+                    launch_level_hdirect(sab, d_frames, fsz, w, h, nframes, L.h_kern.data(), L.ksize, tmp_of[k], L.w);
                 });
             }
     }
     // OPTFLOW_USE_INITIAL_FLOW: the coarsest level starts from resize(flow0, INTER_AREA) * scale instead of zero
     const float *init_cur = nullptr;
-    if (d_init) {
+    if (d_init && iterate) {
         const Level &Lc = c->lv[nlev];
         if (nlev == 0)   // same size: resize() copies, scale = 1
             HIP_TRY(hipMemcpyAsync(ws.flowA, d_init, fsz * 2 * sizeof(float) * npairs, hipMemcpyDeviceToDevice, s));
@@ -421,35 +462,40 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
         const bool lds_ok = (size_t)(w + 2 * (L.ksize / 2)) * 4 * 33 / 32 + 4 * (size_t)L.ksize + 64 <= 60 * 1024;
         if (march && L.w == w && L.h == h && L.ksize == 3) {
             // scale 1: 3-tap blur fused into the polynomial expansion, frames read directly
-            timed(c, s, OFARN_STAGE_POLYEXP, k, ufr, [&] {
-                launch_polyexp_march(s, d_frames, fsz, 1, ws.R, L.w, L.h, nframes, c->poly, L.h_kern3);
+            timed(c, sab, OFARN_STAGE_POLYEXP, k, ufr, [&] {
+                launch_polyexp_march(sab, d_frames, fsz, 1, R_ab(k), L.w, L.h, nframes, c->poly, L.h_kern3);
             });
         } else if (!c->force_generic && nframes >= c->direct_min_frames &&
                    level_direct_supported(d_frames, w, h, L.w, L.h, L.ksize)) {
             // exact 1/2, 1/4, 1/8 levels: row pass + column pass + resize in one kernel straight from the frames
-            timed(c, s, OFARN_STAGE_LEVEL_V, k, ufr, [&] {
-                launch_level_direct(s, d_frames, fsz, w, h, nframes, L.h_kern.data(), L.ksize, ws.I, L.w, L.h, c->row_small_symm);
+            timed(c, sab, OFARN_STAGE_LEVEL_V, k, ufr, [&] {
+                launch_level_direct(sab, d_frames, fsz, w, h, nframes, L.h_kern.data(), L.ksize, ws.I, L.w, L.h, c->row_small_symm);
             });
-            timed(c, s, OFARN_STAGE_POLYEXP, k, ufr, [&] {
-                if (march) launch_polyexp_march(s, ws.I, npx, 0, ws.R, L.w, L.h, nframes, c->poly, L.h_kern3);
-                else launch_polyexp(s, ws.I, ws.R, L.w, L.h, nframes, c->poly);
+            timed(c, sab, OFARN_STAGE_POLYEXP, k, ufr, [&] {
+                if (march) launch_polyexp_march(sab, ws.I, npx, 0, R_ab(k), L.w, L.h, nframes, c->poly, L.h_kern3);
+                else launch_polyexp(sab, ws.I, R_ab(k), L.w, L.h, nframes, c->poly);
             });
         } else {
             float *tmpk = tmp_of[k] ? tmp_of[k] : ws.tmp;
             if (!tmp_of[k])
-                timed(c, s, OFARN_STAGE_LEVEL_H, k, ufr, [&] {
+                timed(c, sab, OFARN_STAGE_LEVEL_H, k, ufr, [&] {
                     if (!c->force_generic && lds_ok)
-                        launch_level_hpass_lds(s, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, ws.tmp, c->row_small_symm);
+                        launch_level_hpass_lds(sab, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, ws.tmp, c->row_small_symm);
                     else
-                        launch_level_hpass(s, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, ws.tmp, c->row_small_symm);
+                        launch_level_hpass(sab, d_frames, fsz, w, h, nframes, L.d_kern, L.ksize, L.d_xofs, L.w, ws.tmp, c->row_small_symm);
                 });
-            timed(c, s, OFARN_STAGE_LEVEL_V, k, ufr, [&] {
-                launch_level_vpass(s, tmpk, h, L.w, L.h, nframes, L.d_kern, L.ksize, L.d_xa, L.d_yofs, L.d_ya, ws.I);
+            timed(c, sab, OFARN_STAGE_LEVEL_V, k, ufr, [&] {
+                launch_level_vpass(sab, tmpk, h, L.w, L.h, nframes, L.d_kern, L.ksize, L.d_xa, L.d_yofs, L.d_ya, ws.I);
             });
-            timed(c, s, OFARN_STAGE_POLYEXP, k, ufr, [&] {
-                if (march) launch_polyexp_march(s, ws.I, npx, 0, ws.R, L.w, L.h, nframes, c->poly, L.h_kern3);
-                else launch_polyexp(s, ws.I, ws.R, L.w, L.h, nframes, c->poly);
+            timed(c, sab, OFARN_STAGE_POLYEXP, k, ufr, [&] {
+                if (march) launch_polyexp_march(sab, ws.I, npx, 0, R_ab(k), L.w, L.h, nframes, c->poly, L.h_kern3);
+                else launch_polyexp(sab, ws.I, R_ab(k), L.w, L.h, nframes, c->poly);
             });
+        }
+        if (!iterate) continue;      // streaming, first frame: nothing to pair it with yet
+        if (overlap) {
+            HIP_TRY(hipEventRecord(c->ev_level[k], sab));
+            HIP_TRY(hipStreamWaitEvent(s, c->ev_level[k], 0));
         }
         if (fused) {
             // stages (E +) C + D fused per iteration; flow ping-pongs between two buffers, the last
@@ -463,11 +509,11 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
                 const int mode = i == 0 ? (prev ? 1 : (cur ? 2 : 0)) : 2;
                 timed(c, s, OFARN_STAGE_FLOW_ITER, k, upx, [&] {
                     if (gauss)
-                        launch_flow_iter_gauss(s, ws.R, fstep, cur, out, L.w, L.h, npairs, c->prm.winsize, c->h_gwin.data(), mode,
+                        launch_flow_iter_gauss(s, R_it(k), fstep, cur, out, L.w, L.h, npairs, c->prm.winsize, c->h_gwin.data(), mode,
                                                prev, pw, ph, L.d_fxofs, L.d_fxa, L.d_fyofs, L.d_fya, mul);
                     else
-                        launch_flow_iter(s, ws.R, fstep, cur, out, L.w, L.h, npairs, c->prm.winsize, mode, prev, pw, ph,
-                                         L.d_fxofs, L.d_fxa, L.d_fyofs, L.d_fya, mul);
+                        launch_flow_iter(s, R_it(k), fstep, cur, out, L.w, L.h, npairs, c->prm.winsize, mode, prev, pw, ph,
+                                         L.d_fxofs, L.d_fxa, L.d_fyofs, L.d_fya, mul, c->tile_mode);
                 });
                 cur = out;
             }
@@ -484,18 +530,18 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
                 launch_flow_upsample(s, prev, pw, ph, flow, L.w, L.h, npairs, L.d_fxofs, L.d_fxa, L.d_fyofs,
                                      L.d_fya, mul);
             });
-        timed(c, s, OFARN_STAGE_MATRICES, k, upx, [&] { launch_update_matrices(s, ws.R, fstep, flow, ws.M, L.w, L.h, npairs); });
+        timed(c, s, OFARN_STAGE_MATRICES, k, upx, [&] { launch_update_matrices(s, R_it(k), fstep, flow, ws.M, L.w, L.h, npairs); });
         for (int i = 0; i < c->prm.iterations; i++) {
             timed(c, s, OFARN_STAGE_BLUR_SOLVE, k, upx, [&] {
                 if (gauss) launch_gauss_solve(s, ws.M, flow, L.w, L.h, npairs, c->prm.winsize, c->d_gwin);
                 else launch_blur_solve(s, ws.M, flow, L.w, L.h, npairs, c->prm.winsize);
             });
             if (i < c->prm.iterations - 1)
-                timed(c, s, OFARN_STAGE_MATRICES, k, upx, [&] { launch_update_matrices(s, ws.R, fstep, flow, ws.M, L.w, L.h, npairs); });
+                timed(c, s, OFARN_STAGE_MATRICES, k, upx, [&] { launch_update_matrices(s, R_it(k), fstep, flow, ws.M, L.w, L.h, npairs); });
         }
         prev = flow; pw = L.w; ph = L.h;
     }
-    if ((d_mask || d_v) && c->P > 0) {
+    if (iterate && (d_mask || d_v) && c->P > 0) {
         if (!d_mask || !d_v) return fail(OFARN_E_INVALID, "danger mask and v must be given together");
         timed(c, s, OFARN_STAGE_GRID_FILTER, 0, (double)c->P * npairs, [&] {
             launch_grid_filter(s, prev, w, h, npairs, c->d_pts, c->P, c->prm.filter_variant, d_mask, d_v, nullptr);
@@ -541,11 +587,21 @@ int ensure_staging(ofarn_ctx *c, size_t frames_bytes, size_t flow_bytes, size_t 
 
 // Grow-only reservation (sizes in floats; 0 = leave alone).  Growing frees the old buffer first, which waits for
 // the device: it happens on the first call of a shape, not per call.
-int ws_reserve(ofarn_ctx *c, int wi, size_t tmp, size_t I, size_t R, size_t M, size_t flow)
+bool stream_is_capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
+}
+
+int ws_reserve(ofarn_ctx *c, int wi, size_t tmp, size_t I, size_t R, size_t M, size_t flow, bool capturing)
 {
     ofarn_ctx::Workspace &ws = c->ws[wi];
     auto grow = [&](float **p, size_t *cap, size_t need, const char *what) -> int {
         if (need <= *cap) return OFARN_OK;
+        if (capturing)
+            return fail(OFARN_E_INVALID, "workspace buffer %s would have to grow while the stream is being captured: run the call once "
+                        "(or ofarn_reserve) before capturing", what);
         if (*p) { (void)hipFree(*p); c->ws_bytes -= *cap * sizeof(float) + 256; *p = nullptr; *cap = 0; }
         const size_t bytes = need * sizeof(float) + 256;
         if (hipMalloc((void **)p, bytes) != hipSuccess) {
@@ -647,6 +703,8 @@ int ofarn_create(const ofarn_params *params, int device, int max_w, int max_h, i
     }
     if (const char *e = getenv("OFARN_DIRECT_MIN_FRAMES")) c->direct_min_frames = atoi(e);
     if (const char *e = getenv("OFARN_ROW_LTR")) c->row_small_symm = e[0] == '1' ? 0 : 1;
+    if (const char *e = getenv("OFARN_TILE")) c->tile_mode = e[0] != '0';
+    if (const char *e = getenv("OFARN_STREAM_ZERO_COPY")) c->stream_zero_copy = e[0] != '0';
     if (!poly_prepare(params->poly_n, params->poly_sigma, c->poly)) {
         delete c;
         return fail(OFARN_E_INVALID, "poly_n out of range");
@@ -694,6 +752,9 @@ void ofarn_destroy(ofarn_ctx *c)
         for (float *p : {ws.tmp, ws.I, ws.R, ws.M, ws.flowA, ws.flowB}) if (p) (void)hipFree(p);
     if (c->st_flow) (void)hipFree(c->st_flow);
     if (c->d_gwin) (void)hipFree(c->d_gwin);
+    if (c->stream_state.R) (void)hipFree(c->stream_state.R);
+    for (uint8_t *p : {c->stream_state.d_frame, c->stream_state.d_bgr}) if (p) (void)hipFree(p);
+    for (hipEvent_t e : c->ev_level) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; i++) {
         if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -709,6 +770,53 @@ void ofarn_destroy(ofarn_ctx *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int ofarn_set_option(ofarn_ctx *c, const char *name, int value)
+{
+    if (!c || !name) return fail(OFARN_E_INVALID, "ctx or name is NULL");
+    const std::string n(name);
+    if (n == "tile") c->tile_mode = value < 0 ? -1 : (value != 0);
+    else if (n == "force_generic") c->force_generic = value != 0;
+    else if (n == "row_ltr") c->row_small_symm = value ? 0 : 1;
+    else if (n == "direct_min_frames") c->direct_min_frames = value;
+    else if (n == "single_stream") c->dual = value == 0;
+    else if (n == "stream_zero_copy") c->stream_zero_copy = value != 0;
+    else if (n == "stream_overlap") c->stream_overlap = value != 0;
+    else if (n == "debug_fail_wave") c->debug_fail_wave = value;
+    else return fail(OFARN_E_INVALID, "unknown option '%s'", name);
+    return OFARN_OK;
+}
+
+int ofarn_reserve(ofarn_ctx *c, int w, int h, int n_pairs, int pairs_mode)
+{
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    if (n_pairs < 1) return fail(OFARN_E_INVALID, "n_pairs must be >= 1");
+    if (pairs_mode != OFARN_PAIRS_INDEPENDENT && pairs_mode != OFARN_PAIRS_CONSECUTIVE)
+        return fail(OFARN_E_INVALID, "pairs_mode must be 0 or 1");
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = make_plan(c, w, h))) return rc;
+    const int np = n_pairs < c->max_batch ? n_pairs : c->max_batch;          // a wave never holds more
+    const int nframes = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? np + 1 : 2 * np;
+    const bool gauss = (c->prm.flags & OFARN_FLAG_FARNEBACK_GAUSSIAN) != 0;
+    const bool fused = !c->force_generic && c->prm.iterations >= 1 &&
+                       (gauss ? flow_iter_gauss_supported(c->prm.winsize) : flow_iter_supported(c->prm.winsize));
+    const size_t M_need = fused ? 0 : (size_t)np * w * h * 5;
+    const int nws = (c->dual && n_pairs > c->max_batch) ? 2 : 1;
+    for (int wi = 0; wi < nws; wi++) {
+        if (wi == 1 && alloc_workspace(c, 1)) return OFARN_E_NOMEM;
+        // frames aligned for the direct level kernels (what hipMalloc / torch give) and not: reserve for the larger of the two
+        size_t tmp = 0, I = 0;
+        for (uintptr_t a : {(uintptr_t)256, (uintptr_t)1}) {
+            WavePlan wp;
+            plan_wave(c, reinterpret_cast<const uint8_t *>(a), nframes, w, h, wp);
+            tmp = std::max(tmp, wp.tmp_need);
+            I = std::max(I, wp.I_need);
+        }
+        if ((rc = ws_reserve(c, wi, tmp, I, 0, M_need, 0))) return rc;
+    }
+    return OFARN_OK;
 }
 
 double ofarn_last_device_ms(const ofarn_ctx *c) { return c ? c->last_ms : 0; }
@@ -854,14 +962,20 @@ int calc_batch_device_impl(ofarn_ctx *c, const uint8_t *d_frames, bool bgr, int 
         rc = run_wave(c, ws_stream, wave_frames, np, pairs_mode, w, h, wave_flow,
                       d_mask ? d_mask + (size_t)p0 * c->P : nullptr, d_v ? d_v + (size_t)p0 * c->P : nullptr,
                       dual ? wi : 0, use_init ? wave_flow : nullptr);
-        if (rc) return rc;
+        if (rc) break;      // waves already enqueued keep running: the join and the call's event below must still happen
     }
+    // Join the two internal streams back into the caller's and record the call's event on EVERY path, the failing one
+    // included: an earlier wave may still be running on an internal stream with the shared workspace, and the next call on
+    // this context (or a stream capture the caller has open) must be ordered behind it.
+    int jrc = OFARN_OK;
     if (dual)
-        for (int i = 0; i < 2; i++) {
-            HIP_TRY(hipEventRecord(c->ev_join[i], c->aux[i]));
-            HIP_TRY(hipStreamWaitEvent(s, c->ev_join[i], 0));
-        }
-    return end_call(c, s);
+        for (int i = 0; i < 2; i++)
+            if (hipEventRecord(c->ev_join[i], c->aux[i]) != hipSuccess || hipStreamWaitEvent(s, c->ev_join[i], 0) != hipSuccess) {
+                (void)hipGetLastError();
+                if (!rc && !jrc) jrc = fail(OFARN_E_HIP, "joining the internal streams failed");
+            }
+    const int erc = end_call(c, s);
+    return rc ? rc : (jrc ? jrc : erc);
 }
 
 
@@ -919,7 +1033,7 @@ int ofarn_calc_batch(ofarn_ctx *c, const uint8_t *h_frames, int n_frames, int w,
         HIP_TRY(hipEventRecord(c->ev0, c->stream));
         rc = run_wave(c, c->stream, c->st_frames, np, pairs_mode, w, h, c->st_flow, h_mask ? c->st_mask : nullptr,
                       h_mask ? c->st_v : nullptr, 0, use_init ? c->st_flow : nullptr);
-        if (rc) return rc;
+        if (rc) { (void)end_call(c, c->stream); return rc; }
         HIP_TRY(hipEventRecord(c->ev1, c->stream));
         if (h_flow)
             HIP_TRY(hipMemcpyAsync(h_flow + (size_t)p0 * fsz * 2, c->st_flow, (size_t)np * fsz * 2 * sizeof(float),
@@ -955,8 +1069,10 @@ int ofarn_calc(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next, int w
         HIP_TRY(hipMemcpyAsync(c->st_flow, h_flow, fsz * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if ((rc = run_wave(c, c->stream, c->st_frames, 1, OFARN_PAIRS_INDEPENDENT, w, h, c->st_flow, nullptr, nullptr, 0,
-                       use_init ? c->st_flow : nullptr)))
+                       use_init ? c->st_flow : nullptr))) {
+        (void)end_call(c, c->stream);
         return rc;
+    }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipMemcpyAsync(h_flow, c->st_flow, fsz * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

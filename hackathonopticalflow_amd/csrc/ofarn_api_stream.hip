@@ -1,0 +1,234 @@
+// ofarn_api_stream.hip -- streaming session of the C-ABI (include/ofarn.h, ofarn_stream_*): the reference's frame loop
+//     gray = cvtColor(img); flow = calculate_optical_flow(prev_gray, gray); prev_gray = gray      DenseOF.py:510, 519-525
+// hands over ONE new frame per turn.  A context keeps the previous frame's polynomial expansions of every pyramid level on the
+// device (two slots per level, the newest frame goes into the slot the older one does not occupy), so a turn uploads one frame,
+// runs stages A + B once and the iterations of the pair; nothing of the previous frame is re-uploaded or recomputed.
+// Results are those of ofarn_calc on (previous frame, new frame), bit for bit.
+#include "ofarn_host.h"
+
+using namespace ofarn;
+using namespace ofarn_host;
+
+namespace {
+
+// Two R slots per level for the plan of (w, h); resets the session when the frame size changes.
+int stream_prepare(ofarn_ctx *c, int w, int h)
+{
+    ofarn_ctx::Stream &st = c->stream_state;
+    if (st.w == w && st.h == h && st.R && st.off.size() == c->lv.size()) return OFARN_OK;
+    st.have = false;
+    st.cur = 0;
+    st.w = w; st.h = h;
+    st.off.assign(c->lv.size(), 0);
+    size_t need = 0;
+    for (size_t k = 0; k < c->lv.size(); k++) {
+        st.off[k] = need;
+        need += 2 * r_frame_stride((size_t)c->lv[k].w * c->lv[k].h);
+    }
+    if (need > st.cap) {
+        if (st.R) { (void)hipFree(st.R); c->ws_bytes -= st.cap * sizeof(float) + 256; st.R = nullptr; st.cap = 0; }
+        const size_t bytes = need * sizeof(float) + 256;
+        if (hipMalloc((void **)&st.R, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            st.R = nullptr;
+            st.w = st.h = 0;
+            return fail(OFARN_E_NOMEM, "streaming state of %zu bytes does not fit", bytes);
+        }
+        st.cap = need;
+        c->ws_bytes += bytes;
+    }
+    return OFARN_OK;
+}
+
+int grow_u8(ofarn_ctx *c, uint8_t **p, size_t *cap, size_t need, const char *what)
+{
+    if (need <= *cap) return OFARN_OK;
+    if (*p) { (void)hipFree(*p); c->ws_bytes -= *cap + 256; *p = nullptr; *cap = 0; }
+    if (hipMalloc((void **)p, need + 256) != hipSuccess) {
+        (void)hipGetLastError();
+        *p = nullptr;
+        return fail(OFARN_E_NOMEM, "%s of %zu bytes does not fit", what, need);
+    }
+    *cap = need;
+    c->ws_bytes += need + 256;
+    return OFARN_OK;
+}
+
+// One turn on stream s with the new gray frame already on the device.  Returns OFARN_OK (flow written) or
+// OFARN_STREAM_PRIMED (first frame of a session: nothing to pair it with).
+int stream_turn(ofarn_ctx *c, hipStream_t s, const uint8_t *d_gray, int w, int h, float *d_flow, uint8_t *d_mask, uint8_t *d_v)
+{
+    ofarn_ctx::Stream &st = c->stream_state;
+    const bool had = st.have;
+    const bool use_init = (c->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW) != 0;
+    int rc = run_wave(c, s, d_gray, 1, OFARN_PAIRS_CONSECUTIVE, w, h, d_flow, had ? d_mask : nullptr, had ? d_v : nullptr, 0,
+                      (use_init && had) ? d_flow : nullptr, &st);
+    if (rc) {
+        st.have = false;                         // a half-written slot must not be paired with anything
+        if (c->aux[0]) (void)hipStreamSynchronize(c->aux[0]);   // stages A + B may have been left running beside the caller's stream
+        return rc;
+    }
+    st.cur = had ? st.cur ^ 1 : 0;
+    st.have = true;
+    st.turns++;
+    return had ? OFARN_OK : OFARN_STREAM_PRIMED;
+}
+
+int stream_check(ofarn_ctx *c, int w, int h)
+{
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = make_plan(c, w, h))) return rc;
+    return stream_prepare(c, w, h);
+}
+
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+int ofarn_stream_reset(ofarn_ctx *c)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    c->stream_state.have = false;
+    c->stream_state.cur = 0;
+    return OFARN_OK;
+}
+
+int ofarn_stream_primed(const ofarn_ctx *c, int w, int h)
+{
+    if (!c) return 0;
+    const ofarn_ctx::Stream &st = c->stream_state;
+    return st.have && st.w == w && st.h == h;
+}
+
+int ofarn_stream_next_device(ofarn_ctx *c, const uint8_t *d_gray, int w, int h, float *d_flow, uint8_t *d_mask, uint8_t *d_v,
+                             void *hip_stream)
+{
+    int rc = stream_check(c, w, h);
+    if (rc) return rc;
+    if (!d_gray) return fail(OFARN_E_INVALID, "frame is NULL");
+    if ((d_mask == nullptr) != (d_v == nullptr)) return fail(OFARN_E_INVALID, "danger mask and v must be given together");
+    if (c->stream_state.have && !d_flow && !d_mask) return fail(OFARN_E_INVALID, "flow and danger maps are all NULL: nothing to compute");
+    if ((c->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW) && c->stream_state.have && !d_flow)
+        return fail(OFARN_E_INVALID, "OPTFLOW_USE_INITIAL_FLOW needs the flow buffer (it holds the initial flow)");
+    hipStream_t s = pick_stream(c, hip_stream);
+    if ((rc = begin_call(c, s))) return rc;
+    const int turn = stream_turn(c, s, d_gray, w, h, d_flow, d_mask, d_v);
+    rc = end_call(c, s);
+    return turn < 0 ? turn : (rc ? rc : turn);
+}
+
+int ofarn_stream_next_device_bgr(ofarn_ctx *c, const uint8_t *d_bgr, int w, int h, float *d_flow, uint8_t *d_mask, uint8_t *d_v,
+                                 void *hip_stream)
+{
+    int rc = stream_check(c, w, h);
+    if (rc) return rc;
+    if (!d_bgr) return fail(OFARN_E_INVALID, "frame is NULL");
+    if ((d_mask == nullptr) != (d_v == nullptr)) return fail(OFARN_E_INVALID, "danger mask and v must be given together");
+    ofarn_ctx::Stream &st = c->stream_state;
+    const size_t fsz = (size_t)w * h;
+    if ((rc = grow_u8(c, &st.d_frame, &st.frame_cap, fsz, "streaming frame buffer"))) return rc;
+    hipStream_t s = pick_stream(c, hip_stream);
+    if ((rc = begin_call(c, s))) return rc;
+    timed(c, s, OFARN_STAGE_BGR2GRAY, 0, (double)fsz, [&] { launch_bgr2gray(s, d_bgr, st.d_frame, fsz, kGrayB, kGrayG, kGrayR, kGrayShift); });
+    const int turn = stream_turn(c, s, st.d_frame, w, h, d_flow, d_mask, d_v);
+    rc = end_call(c, s);
+    return turn < 0 ? turn : (rc ? rc : turn);
+}
+
+// Host frame in, host flow out; synchronous.  `bgr` != 0: h_frame is packed BGR (3 bytes per pixel, `stride` bytes per row).
+static int stream_next_host(ofarn_ctx *c, const uint8_t *h_frame, int bgr, int w, int h, int stride, float *h_flow,
+                            uint8_t *h_mask, uint8_t *h_v)
+{
+    int rc = stream_check(c, w, h);
+    if (rc) return rc;
+    const int bpp = bgr ? 3 : 1;
+    if (!h_frame) return fail(OFARN_E_INVALID, "frame is NULL");
+    if (stride < w * bpp) return fail(OFARN_E_INVALID, "stride %d < row bytes %d", stride, w * bpp);
+    if ((h_mask == nullptr) != (h_v == nullptr)) return fail(OFARN_E_INVALID, "danger mask and v must be given together");
+    ofarn_ctx::Stream &st = c->stream_state;
+    const bool had = st.have;
+    if (had && !h_flow) return fail(OFARN_E_INVALID, "flow is NULL");
+    const size_t fsz = (size_t)w * h;
+    if ((rc = grow_u8(c, &st.d_frame, &st.frame_cap, fsz, "streaming frame buffer"))) return rc;
+    if (bgr && (rc = grow_u8(c, &st.d_bgr, &st.bgr_cap, fsz * 3, "streaming BGR buffer"))) return rc;
+    if ((rc = ensure_staging(c, 0, fsz * 2 * sizeof(float), h_mask ? (size_t)(c->P > 0 ? c->P : 1) : 0))) return rc;
+    hipStream_t s = c->stream;
+    if ((rc = begin_call(c, s))) return rc;
+    uint8_t *dst = bgr ? st.d_bgr : st.d_frame;
+    if (stride == w * bpp) HIP_TRY(hipMemcpyAsync(dst, h_frame, fsz * bpp, hipMemcpyHostToDevice, s));
+    else HIP_TRY(hipMemcpy2DAsync(dst, (size_t)w * bpp, h_frame, stride, (size_t)w * bpp, h, hipMemcpyHostToDevice, s));
+    const bool use_init = (c->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW) != 0;
+    if (use_init && had) HIP_TRY(hipMemcpyAsync(c->st_flow, h_flow, fsz * 2 * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(c->ev0, s));
+    if (bgr)
+        timed(c, s, OFARN_STAGE_BGR2GRAY, 0, (double)fsz, [&] { launch_bgr2gray(s, st.d_bgr, st.d_frame, fsz, kGrayB, kGrayG, kGrayR, kGrayShift); });
+    // a pinned (ofarn_host_alloc / hipHostMalloc) flow buffer is written by the last iteration kernel itself: no copy behind it
+    float *d_out = c->st_flow;
+    bool direct = false;
+    if (had && !use_init && c->stream_zero_copy) {
+        hipPointerAttribute_t at;
+        void *dp = nullptr;
+        if (hipPointerGetAttributes(&at, h_flow) == hipSuccess && at.type == hipMemoryTypeHost &&
+            hipHostGetDevicePointer(&dp, h_flow, 0) == hipSuccess && dp) {
+            d_out = static_cast<float *>(dp);
+            direct = true;
+        } else (void)hipGetLastError();
+    }
+    const int turn = stream_turn(c, s, st.d_frame, w, h, d_out, h_mask ? c->st_mask : nullptr, h_mask ? c->st_v : nullptr);
+    if (turn < 0) { (void)end_call(c, s); return turn; }
+    HIP_TRY(hipEventRecord(c->ev1, s));
+    if (turn == OFARN_OK) {
+        if (!direct) HIP_TRY(hipMemcpyAsync(h_flow, c->st_flow, fsz * 2 * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (h_mask && c->P > 0) {
+            HIP_TRY(hipMemcpyAsync(h_mask, c->st_mask, c->P, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(h_v, c->st_v, c->P, hipMemcpyDeviceToHost, s));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_ms = ms;
+    rc = end_call(c, s);
+    return rc ? rc : turn;
+}
+
+int ofarn_stream_next(ofarn_ctx *c, const uint8_t *h_gray, int w, int h, int stride, float *h_flow)
+{
+    return stream_next_host(c, h_gray, 0, w, h, stride, h_flow, nullptr, nullptr);
+}
+
+int ofarn_stream_next_bgr(ofarn_ctx *c, const uint8_t *h_bgr, int w, int h, int stride, float *h_flow)
+{
+    return stream_next_host(c, h_bgr, 1, w, h, stride, h_flow, nullptr, nullptr);
+}
+
+int ofarn_stream_next_danger(ofarn_ctx *c, const uint8_t *h_gray, int w, int h, int stride, float *h_flow, uint8_t *h_mask,
+                             uint8_t *h_v)
+{
+    return stream_next_host(c, h_gray, 0, w, h, stride, h_flow, h_mask, h_v);
+}
+
+int ofarn_host_alloc(size_t bytes, void **out)
+{
+    if (!out) return fail(OFARN_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return fail(OFARN_E_NOMEM, "pinned host buffer of %zu bytes could not be allocated", bytes);
+    }
+    return OFARN_OK;
+}
+
+int ofarn_host_free(void *p)
+{
+    if (!p) return OFARN_OK;
+    HIP_TRY(hipHostFree(p));
+    return OFARN_OK;
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

@@ -105,6 +105,25 @@ struct ofarn_ctx {
         std::vector<uint8_t *> pyr;      // pyr[0] unused (level 0 is the caller's frames)
         std::vector<int16_t *> der;
     } lk;
+    // Streaming session (ofarn_stream_*, ofarn_api_stream.hip): the reference's frame loop hands over ONE new frame per turn
+    // and carries the previous one (DenseOF.py:510, 519-525: prev_gray = gray).  The polynomial expansion of the last frame
+    // is kept for every pyramid level in one of two slots; the next frame's goes into the other slot and the iteration
+    // kernels read the pair as (slot cur, the other slot) -- see pair_frames() for the negative frame step.
+    struct Stream {
+        int w = 0, h = 0;
+        bool have = false;              // slot `cur` holds a frame
+        int cur = 0;
+        float *R = nullptr;             // level k: two slots of r_frame_stride(w_k * h_k) floats at R + off[k]
+        size_t cap = 0;                 // floats
+        std::vector<size_t> off;
+        uint8_t *d_frame = nullptr;     // the new gray frame (host entry points / BGR input)
+        uint8_t *d_bgr = nullptr;
+        size_t frame_cap = 0, bgr_cap = 0;
+        unsigned long long turns = 0;
+    } stream_state;
+    int stream_overlap = 1;             // streaming turn: stages A + B on an internal stream beside the iteration chain (run_wave)
+    hipEvent_t ev_level[32] = {nullptr};
+    int stream_zero_copy = 1;           // ofarn_stream_next: let the last kernel write a pinned flow buffer itself (OFARN_STREAM_ZERO_COPY=0: copy)
     // host-API staging (lazy)
     uint8_t *st_frames = nullptr;
     float *st_flow = nullptr;
@@ -115,6 +134,9 @@ struct ofarn_ctx {
     struct ProfRec { int stage, level; double units; hipEvent_t a, b; };
     bool prof_on = false;
     bool force_generic = false;   // OFARN_FORCE_GENERIC=1 or ofarn_set_option: use the unfused kernels only
+    int debug_fail_wave = -1;     // test hook: the (n+1)-th wave from now returns OFARN_E_NOMEM (error-path tests); -1 = off
+    int tile_mode = -1;           // fused iteration: -1 = tile kernel for small grids, marching kernel otherwise; 0 / 1 = never / always
+                                  // the tile kernel (OFARN_TILE when the context is created, ofarn_set_option "tile")
     int row_small_symm = 1;       // GaussianBlur row pass of a 3- or 5-tap kernel in SymmRowSmallFilter's order (oracle
                                   // OFO_ROW_SMALL_SYMM); OFARN_ROW_LTR=1 when the context is created: left to right (rounds 1-2)
     int direct_min_frames = 32;   // k_level_direct marches long strips per thread: below this many frames in a wave the
@@ -142,12 +164,19 @@ int ensure_staging(ofarn_ctx *c, size_t frames_bytes, size_t flow_bytes, size_t 
 int build_area_tab(ofarn_ctx *c, int sw, int sh, int dw, int dh, ofarn::AreaTabHost &out);
 void resize_tables(int ssize, int dsize, std::vector<int> &ofs, std::vector<float> &alpha);
 hipEvent_t prof_event(ofarn_ctx *c);   // nullptr if hipEventCreate fails (the launch then goes untimed)
-// Grow-only reservation of workspace `wi`, sizes in floats (0 = leave alone).  OFARN_E_NOMEM if it does not fit.
-int ws_reserve(ofarn_ctx *c, int wi, size_t tmp, size_t I, size_t R, size_t M, size_t flow);
+// Grow-only reservation of workspace `wi`, sizes in floats (0 = leave alone).  OFARN_E_NOMEM if it does not fit; with
+// `capturing` a buffer that would have to grow is an error instead (growing frees and allocates: not capturable, and a graph
+// captured earlier would keep replaying into the freed buffer).
+int ws_reserve(ofarn_ctx *c, int wi, size_t tmp, size_t I, size_t R, size_t M, size_t flow, bool capturing = false);
+bool stream_is_capturing(hipStream_t s);
 // Call ordering on the shared workspace (see ofarn_ctx::ev_done): begin_call before the first enqueue of an entry
 // point on stream s, end_call behind its last one.
 int begin_call(ofarn_ctx *c, hipStream_t s);
 int end_call(ofarn_ctx *c, hipStream_t s);
+// One wave of the dense schedule (ofarn_api.hip).  With `st` (streaming turn): d_frames is the ONE new frame, its level images and
+// polynomial expansions go to the free slot of st->R, and -- if a previous frame is held -- the pair (previous, new) is iterated.
+int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, int pairs_mode, int w, int h, float *d_flow,
+             uint8_t *d_mask, uint8_t *d_v, int wi = 0, const float *d_init = nullptr, ofarn_ctx::Stream *st = nullptr);
 
 // Runs `launch` and, when profiling is on, brackets it with two events on the same stream.
 template <typename F>

@@ -62,11 +62,11 @@ void launch_gauss_solve(hipStream_t s, const float *M, float *flow, int w, int h
 bool flow_iter_supported(int winsize);
 void launch_flow_iter(hipStream_t s, const float *R, int fstep, const float *flow_in, float *flow_out, int w,
                       int h, int npairs, int winsize, int mode, const float *coarse, int cw, int ch,
-                      const int *d_xofs, const float *d_xa, const int *d_yofs, const float *d_ya, float mul);
+                      const int *d_xofs, const float *d_xa, const int *d_yofs, const float *d_ya, float mul, int tile_mode = -1);
 // The same iteration laid out for latency (kernels_tile.hip): chosen by launch_flow_iter when the marching grid would leave
 // most of the chip empty (a single pair, coarse levels of a small batch).  Bit-identical results.
 bool flow_iter_tile_supported(int winsize);
-bool flow_iter_tile_preferred(long marching_blocks);
+bool flow_iter_tile_preferred(long marching_blocks, int tile_mode);
 void launch_flow_iter_tile(hipStream_t s, const float *R, int fstep, const float *flow_in, float *flow_out, int w, int h,
                            int npairs, int winsize, int mode, const float *coarse, int cw, int ch, const int *d_xofs,
                            const float *d_xa, float mul);

@@ -116,7 +116,21 @@ ABI = {
     "ofarn_flow_arrows": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "ofarn_flow_arrows_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                            C.c_void_p]),
+    "ofarn_stream_next": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ofarn_stream_next_bgr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ofarn_stream_next_danger": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ofarn_stream_next_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]),
+    "ofarn_stream_next_device_bgr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p]),
+    "ofarn_stream_reset": (C.c_int, [C.c_void_p]),
+    "ofarn_stream_primed": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "ofarn_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "ofarn_host_free": (C.c_int, [C.c_void_p]),
+    "ofarn_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ofarn_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
 }
+OFARN_STREAM_PRIMED = 1
 
 
 def _share_hip_runtime_with_torch():
@@ -266,6 +280,27 @@ def _ptr(t, name=None, dtype=None, min_elems=0):
 
 
 _live_engines: "weakref.WeakSet" = weakref.WeakSet()   # every open context, closed at interpreter exit
+_live_pinned: dict = {}                                  # address -> finalizer of every pinned_empty() buffer still alive
+
+
+def pinned_empty(shape, dtype=np.float32) -> np.ndarray:
+    """np.empty in page-locked host memory (ofarn_host_alloc = hipHostMalloc).  Frames read from and flow fields written to
+    such an array need no staging copy; a pinned flow buffer given to stream_next is written by the last kernel itself.
+    The memory is returned when the array (and every view of it) is garbage collected, or at interpreter exit."""
+    lib = load_library()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    p = C.c_void_p()
+    _check(lib.ofarn_host_alloc(max(n, 1), C.byref(p)))
+    addr = p.value
+    buf = (C.c_char * max(n, 1)).from_address(addr)
+    arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+    def _free(a=addr):
+        if _live_pinned.pop(a, None) is not None:
+            lib.ofarn_host_free(C.c_void_p(a))
+    _live_pinned[addr] = weakref.finalize(buf, _free)
+    return arr
 
 
 class FarnebackEngine:
@@ -372,6 +407,78 @@ class FarnebackEngine:
         if return_flow:
             return (mask[0], v[0], iflow[0]) if single else (mask, v, iflow)
         return (mask[0], v[0]) if single else (mask, v)
+
+    def set_option(self, name: str, value: int):
+        """ofarn_set_option: "tile", "force_generic", "row_ltr", "direct_min_frames", "single_stream", "stream_zero_copy"."""
+        _check(self._lib.ofarn_set_option(self._h, name.encode(), int(value)))
+
+    def reserve(self, width, height, n_pairs, pairs_mode=PAIRS_INDEPENDENT):
+        """Grows the workspace now to what a batch of n_pairs pairs will need (required before capturing a call into a HIP graph)."""
+        _check(self._lib.ofarn_reserve(self._h, width, height, n_pairs, pairs_mode))
+
+    # ------------------------------------------------------------------ streaming session (DenseOF.py:510, 519-525)
+    def _flow_out(self, flow, h, w):
+        if (isinstance(flow, np.ndarray) and flow.dtype == np.float32 and flow.shape == (h, w, 2) and flow.flags.c_contiguous
+                and flow.flags.writeable):
+            return flow
+        if self.params.flags & OPTFLOW_USE_INITIAL_FLOW:
+            if flow is None or np.shape(flow) != (h, w, 2):
+                raise ValueError(f"OPTFLOW_USE_INITIAL_FLOW needs `flow` (float32[{h},{w},2]) holding the initial flow")
+            return np.array(flow, np.float32, order="C")
+        return np.empty((h, w, 2), np.float32)
+
+    def stream_next(self, frame, flow=None, want_danger=False):
+        """One turn of the reference's frame loop: hands over the NEW frame only; the previous one is held on the device.
+        `frame`: uint8[H,W] gray or uint8[H,W,3] BGR (converted on the device, DenseOF.py:510).  Returns the flow of
+        (previous frame, frame) -- equal to calc(previous, frame) bit for bit -- or None for the first frame of a session.
+        `flow`: optional float32[H,W,2] output (a pinned_empty() array is written by the GPU directly).  want_danger: returns
+        (flow, mask, v) instead."""
+        a = np.asarray(frame)
+        bgr = a.ndim == 3 and a.shape[2] == 3
+        if not bgr:
+            a = _as_gray(a, "frame")
+        elif a.dtype != np.uint8:
+            raise ValueError(f"frame must be uint8, got {a.dtype}")
+        h, w = a.shape[:2]
+        if a.strides[-1] != 1 or (bgr and a.strides[1] != 3) or a.strides[0] < w * (3 if bgr else 1):
+            a = np.ascontiguousarray(a)
+        primed = bool(self._lib.ofarn_stream_primed(self._h, w, h))
+        out = self._flow_out(flow, h, w) if primed else None
+        optr = C.c_void_p(out.ctypes.data) if out is not None else None
+        if want_danger and not bgr:
+            P = len(grid_points(w, h, self.params.grid_step))
+            mask, v = np.zeros(P, np.uint8), np.zeros(P, np.uint8)
+            rc = self._lib.ofarn_stream_next_danger(self._h, C.c_void_p(a.ctypes.data), w, h, a.strides[0], optr,
+                                                    C.c_void_p(mask.ctypes.data), C.c_void_p(v.ctypes.data))
+        else:
+            if want_danger:
+                raise ValueError("want_danger needs a gray frame")
+            fn = self._lib.ofarn_stream_next_bgr if bgr else self._lib.ofarn_stream_next
+            rc = fn(self._h, C.c_void_p(a.ctypes.data), w, h, a.strides[0], optr)
+        if rc < 0:
+            _raise(rc)
+        if rc == OFARN_STREAM_PRIMED:
+            return (None, None, None) if want_danger else None
+        return (out, mask, v) if want_danger else out
+
+    def stream_next_device(self, d_frame, width, height, d_flow=None, d_mask=None, d_v=None, stream=None, bgr=False) -> bool:
+        """Device-resident turn (torch CUDA tensors or raw addresses), enqueued on `stream`, not synchronised.  Returns True when
+        a flow / danger map was enqueued, False for the priming call."""
+        fn = self._lib.ofarn_stream_next_device_bgr if bgr else self._lib.ofarn_stream_next_device
+        npx = width * height
+        P = len(grid_points(width, height, self.params.grid_step)) if (d_mask is not None or d_v is not None) else 0
+        rc = fn(self._h, _ptr(d_frame, "d_frame", "uint8", npx * (3 if bgr else 1)), width, height,
+                _ptr(d_flow, "d_flow", "float32", npx * 2), _ptr(d_mask, "d_mask", "uint8", P), _ptr(d_v, "d_v", "uint8", P),
+                _stream_arg(stream))
+        if rc < 0:
+            _raise(rc)
+        return rc == OFARN_OK
+
+    def stream_reset(self):
+        _check(self._lib.ofarn_stream_reset(self._h))
+
+    def stream_primed(self, width, height) -> bool:
+        return bool(self._lib.ofarn_stream_primed(self._h, width, height))
 
     # ------------------------------------------------------------------ device-memory entry points
     def calc_batch_device(self, d_frames, n_frames, width, height, pairs_mode=PAIRS_INDEPENDENT,
@@ -628,61 +735,182 @@ def _params_dict(p: OfarnParams):
 
 
 # ---------------------------------------------------------------------------------------------
+# The reference's frame loop as an object
+# ---------------------------------------------------------------------------------------------
+class FlowStream:
+    """``flow = stream.next(gray)`` per frame: the loop of DenseOF.py:491-525 (``prev_gray = gray`` is kept on the device).
+
+    The first frame returns None; every later one the flow of (previous frame, this frame), equal to
+    ``calculate_optical_flow(previous, this)`` bit for bit.  Frames may be gray uint8[H,W] or BGR uint8[H,W,3].  Flow fields are
+    returned in page-locked buffers owned by the stream, two of them used in turn: the array returned by one call stays
+    valid until the call AFTER the next one (``copy=True`` returns private copies instead).  A change of frame size or
+    ``reset()`` starts a new session."""
+
+    def __init__(self, device=0, copy=False, **params):
+        self._params, self._device, self._copy = params, device, copy
+        self._eng = None
+        self._shape = None
+        self._bufs = [None, None]
+        self._turn = 0
+
+    def _engine(self, h, w):
+        if self._eng is None or self._shape != (h, w):
+            if self._eng is not None:
+                self._eng.close()
+            self._eng = FarnebackEngine(w, h, 1, self._device, **self._params)
+            self._shape = (h, w)
+            self._bufs = [pinned_empty((h, w, 2)), pinned_empty((h, w, 2))]
+        return self._eng
+
+    def next(self, frame, want_danger=False):
+        a = np.asarray(frame)
+        if a.ndim not in (2, 3):
+            raise ValueError(f"frame must be uint8[H,W] or uint8[H,W,3], got shape {a.shape}")
+        h, w = a.shape[:2]
+        eng = self._engine(h, w)
+        buf = self._bufs[self._turn & 1]
+        if eng.params.flags & OPTFLOW_USE_INITIAL_FLOW and self._turn > 1:
+            buf[...] = self._bufs[(self._turn - 1) & 1]          # temporal warm start: the previous pair's flow
+        out = eng.stream_next(a, buf, want_danger=want_danger)
+        flow = out[0] if want_danger else out
+        if flow is None:
+            self._turn = 1 if eng.params.flags & OPTFLOW_USE_INITIAL_FLOW else 0
+            if eng.params.flags & OPTFLOW_USE_INITIAL_FLOW:
+                self._bufs[0][...] = 0
+            return out
+        self._turn += 1
+        if self._copy:
+            flow = flow.copy()
+        return (flow, out[1], out[2]) if want_danger else flow
+
+    __call__ = next
+
+    def reset(self):
+        if self._eng is not None:
+            self._eng.stream_reset()
+        self._turn = 0
+
+    @property
+    def last_device_ms(self):
+        return self._eng.last_device_ms if self._eng is not None else 0.0
+
+    def close(self):
+        if self._eng is not None:
+            self._eng.close()
+            self._eng = None
+        self._bufs = [None, None]
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+# ---------------------------------------------------------------------------------------------
 # Drop-in functions with the reference's names
 # ---------------------------------------------------------------------------------------------
-_engines: dict = {}          # key -> _CachedEngine, oldest first
+_engines: dict = {}          # key -> _CachedEngines, oldest first
 _engines_lock = threading.Lock()
+_SLOTS_PER_KEY = 2           # contexts per (shape, device, parameters): two threads with the same shape do not serialise
 
 
-class _CachedEngine:
-    """A cached context plus the lock that serialises its users: an ofarn_ctx must not be used from two threads
-    at once, and eviction may only close it once nobody is inside a call."""
-    __slots__ = ("eng", "lock")
+def _frame_signature(a: np.ndarray):
+    """Cheap fingerprint of a frame: identity of the buffer plus a strided sample of its bytes (about 1/450 of a 1080p frame,
+    ~10 us).  It is only ever compared for the SAME array object, to notice that the caller has overwritten it in place."""
+    return (a.__array_interface__["data"][0], a.shape, a.strides, int(a[::61, ::7].sum(dtype=np.int64)))
+
+
+class _Slot:
+    """One cached context + the lock that serialises its users (an ofarn_ctx must not be used from two threads at once) + what
+    its streaming session holds: a weak reference to the array object that was `next` in the last call and its fingerprint."""
+    __slots__ = ("eng", "lock", "last_ref", "last_sig")
 
     def __init__(self, eng):
         self.eng = eng
         self.lock = threading.Lock()
+        self.last_ref = None
+        self.last_sig = None
+
+    def holds(self, prev) -> bool:
+        return (self.last_ref is not None and isinstance(prev, np.ndarray) and self.last_ref() is prev
+                and self.last_sig == _frame_signature(prev))
+
+    def remember(self, nxt):
+        try:
+            self.last_ref, self.last_sig = weakref.ref(nxt), _frame_signature(nxt)
+        except TypeError:                     # not weak-referenceable (not an ndarray): no reuse next time
+            self.last_ref = self.last_sig = None
+
+
+class _CachedEngines:
+    __slots__ = ("slots",)
+
+    def __init__(self):
+        self.slots = []
 
 
 class _EngineLease:
-    """``with _engine_for(...) as eng:`` -- holds the entry's lock for the duration of the call.  An entry can be evicted
-    (and closed) by another thread between the lookup and the lock; the lease then simply looks the key up again."""
+    """``with _engine_for(...) as eng:`` -- holds one slot's lock for the duration of the call.  Up to _SLOTS_PER_KEY
+    contexts exist per key: a second thread with the same shape gets its own instead of waiting (cv2's function is
+    re-entrant); a third waits.  `prefer`: the frame the caller is about to pass as `prev` -- the slot whose streaming session
+    holds exactly that frame is taken first.  An entry can be evicted (and closed) by another thread between the lookup and
+    the lock; the lease then simply looks the key up again."""
 
-    def __init__(self, key, h, w, device, params):
-        self._key, self._h, self._w, self._device, self._params = key, h, w, device, params
-        self._entry = None
+    def __init__(self, key, h, w, device, params, prefer=None):
+        self._key, self._h, self._w, self._device, self._params, self._prefer = key, h, w, device, params, prefer
+        self._slot = None
 
-    def _lookup(self):
+    def _try(self):
         evicted = None
+        got = None
         with _engines_lock:
             entry = _engines.get(self._key)
             if entry is None:
-                if len(_engines) >= 8:   # bounded cache: drop the oldest context
+                if len(_engines) >= 8:   # bounded cache: drop the oldest key with all its contexts
                     evicted = _engines.pop(next(iter(_engines)))
-                entry = _engines[self._key] = _CachedEngine(FarnebackEngine(self._w, self._h, 1, self._device, **self._params))
+                entry = _engines[self._key] = _CachedEngines()
+            order = sorted(entry.slots, key=lambda sl: not sl.holds(self._prefer)) if self._prefer is not None else entry.slots
+            for sl in order:
+                if sl.eng is not None and sl.lock.acquire(False):
+                    got = sl
+                    break
+            if got is None and len(entry.slots) < _SLOTS_PER_KEY:
+                got = _Slot(FarnebackEngine(self._w, self._h, 1, self._device, **self._params))
+                got.lock.acquire()
+                entry.slots.append(got)
+            wait_on = entry.slots[0] if got is None else None
         if evicted is not None:
-            with evicted.lock:           # waits for a thread that is still inside a call on it
-                if evicted.eng is not None:
-                    evicted.eng.close()
-                    evicted.eng = None
-        return entry
+            for sl in evicted.slots:
+                with sl.lock:            # waits for a thread that is still inside a call on it
+                    if sl.eng is not None:
+                        sl.eng.close()
+                        sl.eng = None
+        return got, wait_on
 
     def __enter__(self) -> FarnebackEngine:
         while True:
-            entry = self._lookup()
-            entry.lock.acquire()
-            if entry.eng is not None:
-                self._entry = entry
-                return entry.eng
-            entry.lock.release()         # closed by an eviction that won the race: look it up (create it) again
+            got, wait_on = self._try()
+            if got is None:              # every context of this key is busy: wait for one, then check it is still open
+                wait_on.lock.acquire()
+                if wait_on.eng is None:
+                    wait_on.lock.release()
+                    continue
+                got = wait_on
+            self._slot = got
+            return got.eng
+
+    @property
+    def slot(self) -> _Slot:
+        return self._slot
 
     def __exit__(self, *a):
-        self._entry.lock.release()
-        self._entry = None
+        self._slot.lock.release()
+        self._slot = None
 
 
-def _engine_for(h, w, device, **params) -> _EngineLease:
-    return _EngineLease((h, w, device, tuple(sorted(params.items()))), h, w, device, params)
+def _engine_for(h, w, device, prefer=None, **params) -> _EngineLease:
+    return _EngineLease((h, w, device, tuple(sorted(params.items()))), h, w, device, params, prefer)
 
 
 def calculate_optical_flow(prev, next, flow=None, pyr_scale=0.5, levels=3, winsize=15, iterations=3,
@@ -695,10 +923,29 @@ def calculate_optical_flow(prev, next, flow=None, pyr_scale=0.5, levels=3, winsi
     if prev_a.shape != next_a.shape:
         raise ValueError(f"prev and next must have the same size, got {prev_a.shape} and {next_a.shape}")
     h, w = prev_a.shape
-    with _engine_for(h, w, device, pyr_scale=float(pyr_scale), levels=int(levels), winsize=int(winsize),
-                     iterations=int(iterations), poly_n=int(poly_n), poly_sigma=float(poly_sigma),
-                     flags=int(flags)) as eng:
-        return eng.calc(prev_a, next_a, flow)
+    lease = _engine_for(h, w, device, prefer=prev if isinstance(prev, np.ndarray) else None,
+                        pyr_scale=float(pyr_scale), levels=int(levels), winsize=int(winsize),
+                        iterations=int(iterations), poly_n=int(poly_n), poly_sigma=float(poly_sigma), flags=int(flags))
+    with lease as eng:
+        # The reference calls this once per frame with prev = the array that was `next` one call earlier (DenseOF.py:519-525:
+        # prev_gray = gray).  The context's streaming session then still holds that frame on the device -- level images and
+        # polynomial expansions included -- and only `next` is uploaded and expanded.  Anything else (another array, the same
+        # array overwritten in place, another thread's context) starts a new session from `prev`: same result, no saving.
+        slot = lease.slot
+        if not (slot.holds(prev) and eng.stream_primed(w, h)):
+            eng.stream_reset()
+            eng.stream_next(prev_a)
+        try:
+            out = eng.stream_next(next_a, flow)
+        except Exception:
+            slot.last_ref = slot.last_sig = None
+            eng.stream_reset()
+            raise
+        if isinstance(next, np.ndarray):
+            slot.remember(next)
+        else:
+            slot.last_ref = slot.last_sig = None
+        return out
 
 
 def calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags):
@@ -776,10 +1023,11 @@ def close_cached_engines():
         entries = list(_engines.values())
         _engines.clear()
     for e in entries:
-        with e.lock:
-            if e.eng is not None:
-                e.eng.close()
-                e.eng = None
+        for sl in e.slots:
+            with sl.lock:
+                if sl.eng is not None:
+                    sl.eng.close()
+                    sl.eng = None
 
 
 @atexit.register

@@ -31,6 +31,7 @@
 #ifndef OFARN_H
 #define OFARN_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -105,6 +106,39 @@ int ofarn_calc_batch(ofarn_ctx *ctx, const uint8_t *h_frames, int n_frames, int 
 int ofarn_calc_batch_device(ofarn_ctx *ctx, const uint8_t *d_frames, int n_frames, int w, int h,
                             int pairs_mode, float *d_flow, uint8_t *d_mask, uint8_t *d_v,
                             void *hip_stream);
+
+/* ---- streaming session: the reference's frame loop ---------------------------------
+ *     gray = cv2.cvtColor(img, cv2.COLOR_BGR2GRAY)                          DenseOF.py:510
+ *     flow = calculate_optical_flow(prev=prev_gray, next=gray)               DenseOF.py:519-520
+ *     prev_gray = gray                                                       DenseOF.py:525
+ * One NEW frame per call.  The context keeps the previous frame's polynomial expansions of every pyramid level on the
+ * device, so a turn uploads one frame and runs the level build + polynomial expansion once; the result equals
+ * ofarn_calc(previous frame, new frame) bit for bit.  The first frame of a session (after ofarn_create, ofarn_stream_reset or a
+ * change of frame size) has nothing to be paired with: the call stores it and returns OFARN_STREAM_PRIMED (> 0) without
+ * touching the outputs.  Other entry points of the same context (ofarn_calc, ...) may be called in between; they do not
+ * disturb the session.  With OPTFLOW_USE_INITIAL_FLOW the flow buffer is in/out as in ofarn_calc. */
+#define OFARN_STREAM_PRIMED 1
+/* host frame in, host flow out; synchronous.  h_flow float32[h][w][2] (ignored by the priming call).  A flow buffer from
+ * ofarn_host_alloc (pinned) is written by the last kernel directly, without a device-to-host copy behind it. */
+int ofarn_stream_next(ofarn_ctx *ctx, const uint8_t *h_gray, int w, int h, int stride, float *h_flow);
+/* the same from a packed BGR frame (3 bytes per pixel, `stride` bytes per row): replaces DenseOF.py:510 + :520 */
+int ofarn_stream_next_bgr(ofarn_ctx *ctx, const uint8_t *h_bgr, int w, int h, int stride, float *h_flow);
+/* the same with the danger map of the pair (uint8[P] each, together or both NULL; pathfinder_viewer.py:159-176, 204-217) */
+int ofarn_stream_next_danger(ofarn_ctx *ctx, const uint8_t *h_gray, int w, int h, int stride, float *h_flow,
+                             uint8_t *h_mask, uint8_t *h_v);
+/* device-resident: frame, flow and danger maps are HBM addresses; enqueued on hip_stream, not synchronised.  d_flow may be NULL
+ * when only the danger maps are wanted. */
+int ofarn_stream_next_device(ofarn_ctx *ctx, const uint8_t *d_gray, int w, int h, float *d_flow, uint8_t *d_mask,
+                             uint8_t *d_v, void *hip_stream);
+int ofarn_stream_next_device_bgr(ofarn_ctx *ctx, const uint8_t *d_bgr, int w, int h, float *d_flow, uint8_t *d_mask,
+                                 uint8_t *d_v, void *hip_stream);
+/* Forgets the held frame: the next call primes again (a cut in the video, a seek: DenseOF.py:476-481 re-reads prev_gray). */
+int ofarn_stream_reset(ofarn_ctx *ctx);
+/* 1 if the session holds a frame of this size (the next ofarn_stream_next* call will produce a flow), else 0. */
+int ofarn_stream_primed(const ofarn_ctx *ctx, int w, int h);
+/* Page-locked host memory for frames and flow fields (hipHostMalloc): transfers to and from it need no staging copy. */
+int ofarn_host_alloc(size_t bytes, void **out);
+int ofarn_host_free(void *p);
 
 /* ---- frame front end ------------------------------------------------------
  * cv2.cvtColor(img, cv2.COLOR_BGR2GRAY) on uint8 frames (DenseOF.py:481, 510): OpenCV 4.x fixed point,
@@ -190,6 +224,21 @@ int ofarn_grid_filter_device(ofarn_ctx *ctx, const float *d_flow, int n, int w, 
  * level 0 first; returns the number of scales (levels+1 after cropping).  optflowgf.cpp calc(). */
 int ofarn_level_plan(const ofarn_params *params, int w, int h, int cap, int *lw, int *lh, int *ksize,
                      double *sigma);
+
+/* Grows the workspace NOW to what a batch call of n_pairs pairs of w x h frames will need (level plan, row-pass and
+ * level-image buffers, the matrix buffer of the unfused path, the second workspace of multi-wave batches), so that the call
+ * itself allocates nothing.  Needed before a device entry point is recorded into a HIP graph (hipStreamBeginCapture): a
+ * call whose workspace would have to grow during capture fails with OFARN_E_INVALID, and no later call may grow the
+ * workspace while a captured graph that uses it is alive ("HIP graphs"). */
+int ofarn_reserve(ofarn_ctx *ctx, int w, int h, int n_pairs, int pairs_mode);
+
+/* Per-context switches (diagnostics, A/B runs, tests); the environment variable of the same meaning is read once, by
+ * ofarn_create.  name: "tile" (-1 choose by grid size / 0 never / 1 always use the tile iteration kernel; OFARN_TILE),
+ * "force_generic" (OFARN_FORCE_GENERIC), "row_ltr" (OFARN_ROW_LTR), "direct_min_frames" (OFARN_DIRECT_MIN_FRAMES),
+ * "single_stream" (OFARN_SINGLE_STREAM), "stream_zero_copy" (OFARN_STREAM_ZERO_COPY), "stream_overlap" (streaming turn: level
+ * build + polynomial expansion on an internal stream beside the iteration chain; default 1), "debug_fail_wave" (test hook: the
+ * (value+1)-th wave from now fails with OFARN_E_NOMEM; -1 = off). */
+int ofarn_set_option(ofarn_ctx *ctx, const char *name, int value);
 
 /* Device time in milliseconds of the most recent host-pointer call (hipEvent, H2D/D2H excluded). */
 double ofarn_last_device_ms(const ofarn_ctx *ctx);

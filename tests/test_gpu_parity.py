@@ -42,9 +42,12 @@ def H():
 def iter_kernel(request, monkeypatch):
     """The fused iteration exists twice with identical results: the marching kernel (throughput; chosen when its grid fills
     the chip) and the tile kernel (latency; chosen for small grids).  Left alone, a single small pair would only ever reach
-    the tile kernel, so the pipeline tests force each in turn (OFARN_TILE is read per launch)."""
+    the tile kernel, so the pipeline tests force each in turn (OFARN_TILE, read when a context is created)."""
+    import hackathonopticalflow_amd as HH
     monkeypatch.setenv("OFARN_TILE", "0" if request.param == "march" else "1")
-    return request.param
+    HH.close_cached_engines()          # the switch is read when a context is created: drop the drop-in's cached ones
+    yield request.param
+    HH.close_cached_engines()
 
 
 def epe(a, b):
@@ -1041,7 +1044,9 @@ def test_bench_two_gloo_ranks_share_the_gpu():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["global_pairs"] == 16
+    # two ranks on ONE device: the line reports the distinct devices as n_gpus and the ranks separately
+    assert out["n_gpus"] == 1 and out["ranks"] == 2 and out["scaling"] == "strong" and out["config"]["global_pairs"] == 16
+    assert "share a GPU" in out["config"]["parallelism"]
     assert out["config"]["pairs_per_gpu"] == 8 and out["value"] > 0
     assert out["gathered_danger_maps_checked"] is True
 
@@ -1267,3 +1272,87 @@ def test_device_batch_is_graph_capturable(H, oracle):
                 np.testing.assert_array_equal(d_mask[i].cpu().numpy(), m_ref)
                 np.testing.assert_array_equal(d_v[i].cpu().numpy(), v_ref)
         del g
+
+
+def test_reserve_then_capture_and_capture_guard(H, oracle):
+    """a call recorded into a HIP graph must not allocate.  A fresh context whose workspace would have to grow
+    during capture refuses (ValueError) instead of freeing / allocating buffers that a graph would keep replaying into;
+    ofarn_reserve grows everything up front (level plan, row-pass / level-image buffers, second workspace), after which the very
+    first call can be captured and replays bit-exactly."""
+    torch = pytest.importorskip("torch")
+    w, h, n_pairs = 200, 150, 6
+    frames, _ = translated_pairs(n_pairs, h, w, 4100, max_shift=3)
+    d_frames = torch.from_numpy(frames).cuda()
+    d_flow = torch.empty((n_pairs, h, w, 2), dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    with H.FarnebackEngine(w, h, 4, levels=2) as eng:
+        g = torch.cuda.CUDAGraph()
+        with pytest.raises(ValueError, match="captured"):
+            with torch.cuda.graph(g, stream=side):
+                eng.calc_batch_device(d_frames, 2 * n_pairs, w, h, H.PAIRS_INDEPENDENT, d_flow, stream=side.cuda_stream)
+        del g
+        torch.cuda.synchronize()
+    with H.FarnebackEngine(w, h, 4, levels=2) as eng:
+        w0 = eng.workspace_bytes
+        eng.reserve(w, h, n_pairs)
+        w1 = eng.workspace_bytes
+        assert w1 > w0
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            eng.calc_batch_device(d_frames, 2 * n_pairs, w, h, H.PAIRS_INDEPENDENT, d_flow, stream=side.cuda_stream)
+        assert eng.workspace_bytes == w1                     # nothing grew during capture
+        d_flow.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        got = d_flow.cpu().numpy()
+        for i in range(n_pairs):
+            np.testing.assert_array_equal(got[i], oracle.farneback(frames[2 * i], frames[2 * i + 1], levels=2, box_mode=oracle.BOX_BLOCKED))
+        del g
+        with pytest.raises(ValueError):
+            eng.reserve(w, h, 0)
+        with pytest.raises(ValueError):
+            eng.set_option("no_such_option", 1)
+
+
+@pytest.mark.parametrize("fail_wave", [0, 1, 2])
+def test_error_in_the_middle_of_a_batch_leaves_the_context_usable(H, oracle, fail_wave):
+    """an error in wave k of a multi-wave batch (the waves alternate over two internal streams) used to
+    return without joining those streams or recording the call's event, so the next call could race the still-running waves
+    on the shared workspace.  The failing wave is injected (ofarn_set_option "debug_fail_wave": the kernels of the earlier
+    waves are already enqueued when it fires); the call reports MemoryError, and the NEXT call on the same context -- on
+    another stream, right away -- is correct for every pair."""
+    torch = pytest.importorskip("torch")
+    w, h, n_pairs = 320, 240, 6
+    frames, _ = translated_pairs(n_pairs, h, w, 4200, max_shift=3)
+    other, _ = warped_pairs(n_pairs, h, w, 4300)
+    d_a = torch.from_numpy(frames).cuda()
+    d_b = torch.from_numpy(other).cuda()
+    d_flow = torch.empty((n_pairs, h, w, 2), dtype=torch.float32, device="cuda")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with H.FarnebackEngine(w, h, 2, levels=3) as eng:          # waves of 2 pairs: 3 waves over the two internal streams
+        eng.calc_batch_device(d_a, 2 * n_pairs, w, h, H.PAIRS_INDEPENDENT, d_flow, stream=s1.cuda_stream)   # warm: workspaces exist
+        s1.synchronize()
+        eng.set_option("debug_fail_wave", fail_wave)
+        with pytest.raises(MemoryError, match="injected"):
+            eng.calc_batch_device(d_a, 2 * n_pairs, w, h, H.PAIRS_INDEPENDENT, d_flow, stream=s1.cuda_stream)
+        # no synchronisation here: the next call, on ANOTHER stream, must order itself behind whatever the failed call left running
+        eng.calc_batch_device(d_b, 2 * n_pairs, w, h, H.PAIRS_INDEPENDENT, d_flow, stream=s2.cuda_stream)
+        s2.synchronize()
+        got = d_flow.cpu().numpy()
+        for i in range(n_pairs):
+            np.testing.assert_array_equal(got[i], oracle.farneback(other[2 * i], other[2 * i + 1], levels=3, box_mode=oracle.BOX_BLOCKED))
+    # host entry points: same injected failure, then a correct call
+    a, b = frames[0], frames[1]
+    with H.FarnebackEngine(w, h, 1, levels=3) as eng:
+        eng.set_option("debug_fail_wave", 0)
+        with pytest.raises(MemoryError):
+            eng.calc(a, b)
+        np.testing.assert_array_equal(eng.calc(a, b), oracle.farneback(a, b, levels=3, box_mode=oracle.BOX_BLOCKED))
+        eng.set_option("debug_fail_wave", 1)
+        assert eng.stream_next(a) is None                      # wave 0 of the countdown
+        with pytest.raises(MemoryError):
+            eng.stream_next(b)
+        assert not eng.stream_primed(w, h)                     # a failed turn drops the session
+        assert eng.stream_next(a) is None
+        np.testing.assert_array_equal(eng.stream_next(b), oracle.farneback(a, b, levels=3, box_mode=oracle.BOX_BLOCKED))

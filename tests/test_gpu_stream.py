@@ -1,0 +1,282 @@
+"""GPU parity of the streaming session (ofarn_stream_*, FlowStream, the drop-in's frame reuse): the reference's frame loop
+    gray = cvtColor(img); flow = calculate_optical_flow(prev_gray, gray); prev_gray = gray        DenseOF.py:510, 519-525
+hands over one new frame per turn.  Every turn must equal the pair call -- and therefore the oracle -- bit for bit."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from hackathonopticalflow_amd.synth import translated_pair, warped_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    import hackathonopticalflow_amd as H
+    H.load_library()
+    return H
+
+
+def video(n, h, w, seed):
+    """n frames of a moving scene: each frame is the previous one's `next` of a fresh warp (so consecutive frames differ by a
+    zoom + rotation + sub-pixel shift, like an FPV flight), uint8[n, h, w]."""
+    rng = np.random.default_rng(seed)
+    frames = []
+    a, b, _, _ = warped_pair(h, w, seed, zoom=1.01 + 0.02 * rng.random(), angle_deg=float(rng.uniform(-1, 1)), occluder=False)
+    frames += [a, b]
+    while len(frames) < n:
+        # keep warping the same texture a little further each time
+        _, b, _, _ = warped_pair(h, w, seed, zoom=1.0 + 0.012 * len(frames), angle_deg=0.3 * len(frames),
+                                 shift=(0.7 * len(frames), -0.4 * len(frames)), occluder=False)
+        frames.append(b)
+    return np.stack(frames[:n])
+
+
+@pytest.mark.parametrize("w,h,kw", [(320, 240, dict(levels=3)), (333, 251, dict(levels=2, winsize=9, iterations=2)),
+                                    (200, 150, dict(levels=2, flags=256)), (160, 120, dict(levels=1, poly_n=7, poly_sigma=1.5))])
+def test_six_frame_sequence_bit_exact(H, oracle, w, h, kw):
+    fr = video(6, h, w, 11)
+    with H.FlowStream(**kw) as st:
+        assert st.next(fr[0]) is None
+        for i in range(1, 6):
+            flow = st.next(fr[i])
+            np.testing.assert_array_equal(flow, oracle.farneback(fr[i - 1], fr[i], box_mode=oracle.BOX_BLOCKED, **kw), err_msg=f"pair {i - 1}")
+    # the engine-level call with caller-owned (pageable) output, strided input, and the generic kernels
+    with H.FarnebackEngine(w, h, 1, **kw) as eng:
+        big = np.zeros((6, h, w + 13), np.uint8)
+        big[:, :, :w] = fr
+        assert eng.stream_next(big[0, :, :w]) is None
+        out = np.empty((h, w, 2), np.float32)
+        for i in range(1, 6):
+            got = eng.stream_next(big[i, :, :w], out)
+            assert got is out
+            np.testing.assert_array_equal(got, oracle.farneback(fr[i - 1], fr[i], box_mode=oracle.BOX_BLOCKED, **kw))
+
+
+def test_stream_equals_pair_call_1080p(H, oracle):
+    """Full size, the BASELINE config-2 parameters: a 4-frame stream against ofarn_calc on each pair (and the first pair
+    against the oracle), through pinned buffers (the zero-copy path: the last kernel writes host memory itself)."""
+    w, h = 1920, 1080
+    a, b, _ = translated_pair(h, w, 2001)
+    c, _, _ = translated_pair(h, w, 2002)
+    fr = [a, b, c, a]
+    with H.FlowStream(levels=5) as st, H.FarnebackEngine(w, h, 1, levels=5) as eng:
+        assert st.next(fr[0]) is None
+        for i in range(1, 4):
+            flow = st.next(fr[i])
+            np.testing.assert_array_equal(flow, eng.calc(fr[i - 1], fr[i]))
+            if i == 1:
+                np.testing.assert_array_equal(flow, oracle.farneback(a, b, levels=5, box_mode=oracle.BOX_BLOCKED))
+
+
+def test_zero_copy_and_copy_paths_agree(H, monkeypatch):
+    w, h = 640, 480
+    fr = video(4, h, w, 5)
+    res = {}
+    for zc in ("1", "0"):
+        monkeypatch.setenv("OFARN_STREAM_ZERO_COPY", zc)
+        with H.FlowStream(copy=True) as st:
+            res[zc] = [st.next(f) for f in fr]
+    for x, y in zip(res["1"][1:], res["0"][1:]):
+        np.testing.assert_array_equal(x, y)
+
+
+def test_bgr_frames_and_danger_maps(H, oracle):
+    """BGR frames in (DenseOF.py:510 on the device), danger map of each pair out (pathfinder_viewer.py:159-176, 204-217)."""
+    w, h = 320, 240
+    rng = np.random.default_rng(3)
+    gray = video(4, h, w, 21)
+    bgr = np.stack([np.stack([g, np.roll(g, 3, 1), 255 - g], -1) for g in gray])
+    bgr = (bgr.astype(np.int32) + rng.integers(-3, 4, bgr.shape)).clip(0, 255).astype(np.uint8)
+    g = [oracle.bgr2gray(x) for x in bgr]
+    with H.FlowStream(levels=2) as st:
+        assert st.next(bgr[0]) is None
+        for i in range(1, 4):
+            np.testing.assert_array_equal(st.next(bgr[i]), oracle.farneback(g[i - 1], g[i], levels=2, box_mode=oracle.BOX_BLOCKED))
+    with H.FarnebackEngine(w, h, 1, levels=2) as eng:
+        assert eng.stream_next(gray[0], want_danger=True) == (None, None, None)
+        for i in range(1, 4):
+            flow, mask, v = eng.stream_next(gray[i], want_danger=True)
+            ref = oracle.farneback(gray[i - 1], gray[i], levels=2, box_mode=oracle.BOX_BLOCKED)
+            np.testing.assert_array_equal(flow, ref)
+            m_ref, v_ref = oracle.danger_map_numpy(ref, w, h, 30)
+            np.testing.assert_array_equal(mask, m_ref)
+            np.testing.assert_array_equal(v, v_ref)
+
+
+def test_reset_size_change_and_interleaving(H, oracle):
+    """A new frame size or reset() starts a new session (the next call primes); other entry points of the same context in
+    between (calc at the same or another size, danger_map) do not disturb the held frame."""
+    fr = video(5, 120, 160, 8)
+    big = video(3, 150, 200, 9)
+    kw = dict(levels=2)
+    ref = lambda p, n: oracle.farneback(p, n, box_mode=oracle.BOX_BLOCKED, **kw)
+    with H.FarnebackEngine(200, 150, 1, **kw) as eng:
+        assert eng.stream_next(fr[0]) is None and eng.stream_primed(160, 120) and not eng.stream_primed(200, 150)
+        np.testing.assert_array_equal(eng.stream_next(fr[1]), ref(fr[0], fr[1]))
+        # interleaved pair calls: same size, then another size (the plan is rebuilt), then the grid filter
+        np.testing.assert_array_equal(eng.calc(fr[3], fr[4]), ref(fr[3], fr[4]))
+        np.testing.assert_array_equal(eng.calc(big[0], big[1]), ref(big[0], big[1]))
+        eng.danger_map(np.zeros((150, 200, 2), np.float32))
+        np.testing.assert_array_equal(eng.stream_next(fr[2]), ref(fr[1], fr[2]))       # still holds fr[1]
+        # size change: primes again, at the new size
+        assert eng.stream_next(big[0]) is None
+        np.testing.assert_array_equal(eng.stream_next(big[1]), ref(big[0], big[1]))
+        # back to the first size: the old session is gone
+        assert eng.stream_next(fr[3]) is None
+        np.testing.assert_array_equal(eng.stream_next(fr[4]), ref(fr[3], fr[4]))
+        eng.stream_reset()
+        assert not eng.stream_primed(160, 120)
+        assert eng.stream_next(fr[0]) is None
+        np.testing.assert_array_equal(eng.stream_next(fr[1]), ref(fr[0], fr[1]))
+        with pytest.raises(ValueError):
+            eng.stream_next(np.zeros((300, 300), np.uint8))                            # larger than the context
+        with pytest.raises(ValueError):
+            eng.stream_next(np.zeros((120, 160), np.float32))
+        np.testing.assert_array_equal(eng.stream_next(fr[2]), ref(fr[1], fr[2]))       # a refused call leaves the session alone
+
+
+def test_device_resident_stream_torch(H, oracle):
+    torch = pytest.importorskip("torch")
+    w, h = 320, 240
+    fr = video(5, h, w, 13)
+    dev = torch.device("cuda", 0)
+    d_fr = torch.from_numpy(fr).to(dev)
+    d_bgr = torch.stack([d_fr, d_fr, d_fr], -1).contiguous()       # gray as BGR: cvtColor gives the gray back (coefficients sum to 2^15)
+    flow = torch.empty((h, w, 2), dtype=torch.float32, device=dev)
+    P = len(H.grid_points(w, h, 30))
+    mask = torch.zeros(P, dtype=torch.uint8, device=dev)
+    v = torch.zeros(P, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    with H.FarnebackEngine(w, h, 1, levels=3) as eng:
+        assert eng.stream_next_device(d_fr[0], w, h, flow, mask, v, stream=st) is False
+        for i in range(1, 5):
+            use_bgr = i % 2 == 0
+            assert eng.stream_next_device(d_bgr[i] if use_bgr else d_fr[i], w, h, flow, mask, v, stream=st, bgr=use_bgr) is True
+            torch.cuda.synchronize()
+            ref = oracle.farneback(fr[i - 1], fr[i], levels=3, box_mode=oracle.BOX_BLOCKED)
+            np.testing.assert_array_equal(flow.cpu().numpy(), ref)
+            m_ref, v_ref = oracle.danger_map_numpy(ref, w, h, 30)
+            np.testing.assert_array_equal(mask.cpu().numpy(), m_ref)
+            np.testing.assert_array_equal(v.cpu().numpy(), v_ref)
+        # danger maps only (no flow buffer)
+        assert eng.stream_next_device(d_fr[0], w, h, None, mask, v, stream=st) is True
+        torch.cuda.synchronize()
+        m_ref, _ = oracle.danger_map_numpy(oracle.farneback(fr[4], fr[0], levels=3, box_mode=oracle.BOX_BLOCKED), w, h, 30)
+        np.testing.assert_array_equal(mask.cpu().numpy(), m_ref)
+
+
+def test_initial_flow_warm_start(H, oracle):
+    """OPTFLOW_USE_INITIAL_FLOW in a stream: the flow buffer is in/out as in cv2 (here: the previous pair's flow)."""
+    w, h = 200, 150
+    fr = video(4, h, w, 17)
+    kw = dict(levels=2, flags=4)
+    with H.FarnebackEngine(w, h, 1, **kw) as eng, H.FarnebackEngine(w, h, 1, **kw) as pair:
+        assert eng.stream_next(fr[0], np.zeros((h, w, 2), np.float32)) is None
+        prev_flow = np.zeros((h, w, 2), np.float32)
+        for i in range(1, 4):
+            init = prev_flow.copy()
+            got = eng.stream_next(fr[i], init.copy())
+            want = pair.calc(fr[i - 1], fr[i], init.copy())
+            np.testing.assert_array_equal(got, want)
+            prev_flow = got
+
+
+def test_drop_in_reuses_the_previous_frame(H, oracle, monkeypatch):
+    """calculate_optical_flow called as the reference does (prev = the array that was `next` one call earlier) uploads and
+    expands only the new frame; any other call pattern -- a different array, the same array overwritten in place -- starts a
+    new session.  Results are the oracle's either way."""
+    H.close_cached_engines()
+    resets = []
+    orig = H.FarnebackEngine.stream_reset
+    monkeypatch.setattr(H.FarnebackEngine, "stream_reset", lambda self: (resets.append(1), orig(self))[1])
+    fr = [f.copy() for f in video(6, 120, 160, 23)]
+    ref = lambda p, n: oracle.farneback(p, n, levels=2, box_mode=oracle.BOX_BLOCKED)
+    prev = fr[0]
+    for i in range(1, 4):                                   # the reference's loop
+        np.testing.assert_array_equal(H.calculate_optical_flow(prev, fr[i], levels=2), ref(prev, fr[i]))
+        prev = fr[i]
+    assert len(resets) == 1                                 # only the very first call had to start a session
+    # a copy of the right frame is another object: correct, no reuse
+    np.testing.assert_array_equal(H.calculate_optical_flow(fr[3].copy(), fr[4], levels=2), ref(fr[3], fr[4]))
+    assert len(resets) == 2
+    # the held frame overwritten in place: noticed (strided fingerprint), correct
+    keep = fr[4].copy()
+    fr[4][:] = fr[0]
+    np.testing.assert_array_equal(H.calculate_optical_flow(fr[4], fr[5], levels=2), ref(fr[0], fr[5]))
+    assert len(resets) == 3
+    fr[4][:] = keep
+    # other parameters -> another context; then back: the first context still holds fr[5]
+    np.testing.assert_array_equal(H.calculate_optical_flow(fr[1], fr[2], levels=1), oracle.farneback(fr[1], fr[2], levels=1, box_mode=oracle.BOX_BLOCKED))
+    n0 = len(resets)
+    np.testing.assert_array_equal(H.calculate_optical_flow(fr[5], fr[0], levels=2), ref(fr[5], fr[0]))
+    assert len(resets) == n0
+    # caller-provided flow buffer is filled and returned
+    out = np.empty((120, 160, 2), np.float32)
+    assert H.calculate_optical_flow(fr[0], fr[1], out, levels=2) is out
+    np.testing.assert_array_equal(out, ref(fr[0], fr[1]))
+    H.close_cached_engines()
+
+
+def test_two_threads_same_shape_do_not_share_a_session(H, oracle):
+    """Two threads running the reference's loop on their own videos of the same shape: each gets its own cached context
+    (two per key), sessions never mix, every result is the oracle's."""
+    H.close_cached_engines()
+    vids = [video(5, 120, 160, 31), video(5, 120, 160, 32)]
+    refs = [[oracle.farneback(v[i], v[i + 1], levels=2, box_mode=oracle.BOX_BLOCKED) for i in range(4)] for v in vids]
+    errs = []
+
+    def run(k):
+        try:
+            fr = [f.copy() for f in vids[k]]
+            for rep in range(3):
+                prev = fr[0]
+                for i in range(1, 5):
+                    got = H.calculate_optical_flow(prev, fr[i], levels=2)
+                    if not np.array_equal(got, refs[k][i - 1]):
+                        errs.append((k, rep, i))
+                    prev = fr[i]
+        except Exception as e:      # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    ts = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    H.close_cached_engines()
+
+
+def test_c_abi_stream_return_codes(H):
+    """Raw C-ABI: OFARN_STREAM_PRIMED (1) for the first frame, 0 afterwards, negative + message on bad arguments; pinned memory
+    from ofarn_host_alloc is accepted for frame and flow."""
+    lib = H.load_library()
+    w, h = 160, 120
+    a, b, _ = translated_pair(h, w, 3, max_shift=2)
+    p = H.make_params(levels=2)
+    ctx = C.c_void_p()
+    assert lib.ofarn_create(C.byref(p), 0, w, h, 1, C.byref(ctx)) == 0
+    try:
+        flow = np.empty((h, w, 2), np.float32)
+        vp = lambda x: C.c_void_p(x.ctypes.data)
+        assert lib.ofarn_stream_primed(ctx, w, h) == 0
+        assert lib.ofarn_stream_next(ctx, vp(a), w, h, w, None) == 1            # priming: flow may be NULL
+        assert lib.ofarn_stream_primed(ctx, w, h) == 1
+        assert lib.ofarn_stream_next(ctx, vp(b), w, h, w, None) == -1 and b"flow is NULL" in lib.ofarn_last_error()
+        assert lib.ofarn_stream_next(ctx, vp(b), w, h, w - 1, vp(flow)) == -1 and b"stride" in lib.ofarn_last_error()
+        assert lib.ofarn_stream_next(ctx, vp(b), w, h, w, vp(flow)) == 0
+        with H.FarnebackEngine(w, h, 1, levels=2) as eng:
+            np.testing.assert_array_equal(flow, eng.calc(a, b))
+        pin = C.c_void_p()
+        assert lib.ofarn_host_alloc(h * w * 8, C.byref(pin)) == 0 and pin.value
+        assert lib.ofarn_stream_next(ctx, vp(a), w, h, w, pin) == 0
+        got = np.frombuffer((C.c_char * (h * w * 8)).from_address(pin.value), np.float32).reshape(h, w, 2).copy()
+        with H.FarnebackEngine(w, h, 1, levels=2) as eng:
+            np.testing.assert_array_equal(got, eng.calc(b, a))
+        assert lib.ofarn_host_free(pin) == 0
+        assert lib.ofarn_stream_reset(ctx) == 0 and lib.ofarn_stream_primed(ctx, w, h) == 0
+    finally:
+        lib.ofarn_destroy(ctx)

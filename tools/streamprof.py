@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Per-kernel hipEvent table of ONE streaming turn (one new 1080p frame): where the single-pair latency goes.
+
+    python tools/streamprof.py [--w 1920 --h 1080 --levels 5 --reps 20]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--w", type=int, default=1920)
+    ap.add_argument("--h", type=int, default=1080)
+    ap.add_argument("--levels", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=20)
+    a = ap.parse_args()
+    import hackathonopticalflow_amd as ofa
+    from hackathonopticalflow_amd.synth import translated_pair
+    f0, f1, _ = translated_pair(a.h, a.w, 2001)
+    f2, f3, _ = translated_pair(a.h, a.w, 2002)
+    fr = [f0, f1, f2, f3]
+    eng = ofa.FarnebackEngine(a.w, a.h, 1, 0, levels=a.levels)
+    out = ofa.pinned_empty((a.h, a.w, 2))
+    eng.stream_next(fr[0])
+    for i in range(5):
+        eng.stream_next(fr[(i + 1) % 4], out)
+    for zc in (1, 0):
+        eng.set_option("stream_zero_copy", zc)
+        ts, dev = [], []
+        for i in range(a.reps):
+            t0 = time.perf_counter()
+            eng.stream_next(fr[(i + 2) % 4], out)
+            ts.append((time.perf_counter() - t0) * 1e3)
+            dev.append(eng.last_device_ms)
+        print(f"zero_copy={zc}: wall median {np.median(ts):.4f} ms (min {min(ts):.4f}), device {np.median(dev):.4f} ms")
+    eng.profile_enable(True)
+    for i in range(a.reps):
+        eng.stream_next(fr[(i + 2) % 4], out)
+    rows = eng.profile_read()
+    tot = sum(r["ms"] for r in rows) / a.reps
+    print(f"per-kernel events, copy path, mean of {a.reps} turns: sum {tot * 1e3:.1f} us in {sum(r['launches'] for r in rows) // a.reps} launches")
+    for r in sorted(rows, key=lambda r: (-r["level"] if r["level"] < 31 else -99, r["stage"])):
+        print(f"  {r['stage']:12s} L{r['level']:<2d} x{r['launches'] // a.reps}  {r['ms'] / a.reps * 1e3:8.1f} us")
+
+
+if __name__ == "__main__":
+    main()
