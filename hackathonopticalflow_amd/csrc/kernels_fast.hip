@@ -91,6 +91,16 @@ __device__ __forceinline__ double wave_shl1(double edge, double src)
     return __hiloint2double(hi, lo);
 }
 
+// 32-bit whole-wave shifts: lane i <- src[lane i+1] (lane 63 keeps `edge`) and lane i <- src[lane i-1] (lane 0 keeps `edge`)
+__device__ __forceinline__ unsigned wave_shl1_u32(unsigned edge, unsigned src)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)src, 0x130, 0xF, 0xF, false);
+}
+__device__ __forceinline__ unsigned wave_shr1_u32(unsigned edge, unsigned src)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)edge, (int)src, 0x138, 0xF, 0xF, false);
+}
+
 template <int M_, int MODE>   // MODE 0: flow_in == 0;  1: flow_in = upsample(coarse)*mul;  2: flow_in from HBM
 __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
                                                           const float2 *__restrict__ flow_in,
@@ -498,7 +508,17 @@ __global__ __launch_bounds__(FI_THREADS) void k_polyexp_march(const void *__rest
     //   SRC 0: the float level image.  SRC 1: level 0, 3-tap blur state (row pass of rows yy-1, yy, yy+1) from the bytes.
     const int xl = reflect101(xc - 1, w), xr = reflect101(xc + 1, w);
     float rpm = 0.f, rpc = 0.f, rpp = 0.f, icur = 0.f, pf = 0.f;
-    uint8_t nl = 0, nc = 0, nr = 0;
+    // SRC 1, marching: ONE byte per lane and row.  A lane's left / right neighbours are the bytes its neighbouring lanes have
+    // just loaded (whole-wave DPP shifts), except where a neighbouring lane does not hold the neighbouring pixel: lanes 0 and 63
+    // of a wave (the neighbour is in another wave or block) and the lanes at or beyond the frame's left / right edge (clamped
+    // columns, reflect-101 neighbours -- there xl == xr).  Those few lanes fetch ONE extra byte, f[xe], in a second, almost empty
+    // load (round 2 loaded f[xl], f[xc], f[xr] in every lane: three full byte-load instructions per row for one byte of input;
+    // the texture addresser takes as long for 64 bytes as for 64 float4).
+    const int lane = tid & 63;
+    const bool edge_col = x <= 0 || x >= w - 1;              // xl == xr here
+    const bool need_e = edge_col || lane == 0 || lane == 63;
+    const int xe = (lane == 63 && !edge_col) ? xr : xl;
+    unsigned nc = 0, ne = 0;
     int ry = -0x40000000;
     auto rowpass3 = [&](uint8_t a, uint8_t b, uint8_t cc) {
         float s = k0 * (float)a;
@@ -515,13 +535,18 @@ __global__ __launch_bounds__(FI_THREADS) void k_polyexp_march(const void *__rest
         if (SRC == 0) pf = img[(size_t)yy * w + xc];
         else if (yy == ry + 1) {                         // uniform; the other cases need no new row or take the slow path
             const uint8_t *f = frm + (size_t)reflect101(yy + 1, h) * w;
-            nl = f[xl]; nc = f[xc]; nr = f[xr];
+            nc = f[xc];
+            if (need_e) ne = f[xe];
         }
     };
     auto finish = [&](int yy) -> float {
         if (SRC == 0) return pf;
         if (yy == ry) return icur;
-        if (yy == ry + 1) { rpm = rpc; rpc = rpp; rpp = rowpass3(nl, nc, nr); }
+        if (yy == ry + 1) {
+            const unsigned dl = wave_shr1_u32(ne, nc), dr = wave_shl1_u32(ne, nc);   // lane 0 / 63 keep their own extra byte
+            const uint8_t nl = (uint8_t)(edge_col ? ne : dl), nr = (uint8_t)(edge_col ? ne : dr);
+            rpm = rpc; rpc = rpp; rpp = rowpass3(nl, (uint8_t)nc, nr);
+        }
         else { rpm = rowpass(reflect101(yy - 1, h)); rpc = rowpass(yy); rpp = rowpass(reflect101(yy + 1, h)); }
         ry = yy;
         icur = k1 * rpc + k2 * (rpp + rpm);

@@ -929,16 +929,24 @@ int calc_batch_device_impl(ofarn_ctx *c, const uint8_t *d_frames, bool bgr, int 
     const bool use_init = (c->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW) != 0;
     if (use_init && !d_flow) return fail(OFARN_E_INVALID, "OPTFLOW_USE_INITIAL_FLOW needs the flow buffer (it holds the initial flow)");
     HIP_TRY(hipSetDevice(c->device));
-    if ((rc = make_plan(c, w, h))) return rc;
     hipStream_t s = pick_stream(c, hip_stream);
+    // Recorded into a HIP graph?  Then nothing below may allocate, free or copy synchronously: refuse BEFORE the first such
+    // call (it would invalidate the caller's capture) whatever a warm-up call or ofarn_reserve would have prepared.
+    const bool capturing = stream_is_capturing(s);
+    if (capturing && (c->plan_w != w || c->plan_h != h || (bgr && !c->gray[0])))
+        return fail(OFARN_E_INVALID, "the stream is being captured and this context has not seen %dx%d%s frames yet: run the call once, "
+                    "or ofarn_reserve, before capturing", w, h, bgr ? " BGR" : "");
+    if ((rc = make_plan(c, w, h))) return rc;
     if ((rc = begin_call(c, s))) return rc;
     const size_t fsz = (size_t)w * h;
     const int fstep = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? 1 : 2;
     const int nwaves = (n_pairs + c->max_batch - 1) / c->max_batch;
     if (bgr && (rc = ensure_gray(c, 0))) return rc;
     // More than one wave: alternate them over two internal streams (each with its own workspace), forked
-    // from and joined back into the caller's stream with events.  Per-kernel profiling keeps one stream.
-    const bool dual = c->dual && nwaves > 1 && !c->prof_on && alloc_workspace(c, 1) == 0 && (!bgr || ensure_gray(c, 1) == 0);
+    // from and joined back into the caller's stream with events.  Per-kernel profiling keeps one stream.  (During capture
+    // only if the second workspace already exists.)
+    const bool dual = c->dual && nwaves > 1 && !c->prof_on && (!capturing || (c->ws[1].R && (!bgr || c->gray[1]))) &&
+                      alloc_workspace(c, 1) == 0 && (!bgr || ensure_gray(c, 1) == 0);
     if (dual) {
         HIP_TRY(hipEventRecord(c->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));

@@ -74,11 +74,15 @@ int stream_turn(ofarn_ctx *c, hipStream_t s, const uint8_t *d_gray, int w, int h
     return had ? OFARN_OK : OFARN_STREAM_PRIMED;
 }
 
-int stream_check(ofarn_ctx *c, int w, int h)
+int stream_check(ofarn_ctx *c, int w, int h, hipStream_t s = nullptr, bool device_entry = false)
 {
     int rc = check_size(c, w, h);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
+    const ofarn_ctx::Stream &st = c->stream_state;
+    if (device_entry && stream_is_capturing(s) && (c->plan_w != w || c->plan_h != h || st.w != w || st.h != h || !st.R))
+        return fail(OFARN_E_INVALID, "the stream is being captured and this context's streaming session has not seen %dx%d frames yet: "
+                    "run one turn before capturing", w, h);
     if ((rc = make_plan(c, w, h))) return rc;
     return stream_prepare(c, w, h);
 }
@@ -106,7 +110,8 @@ int ofarn_stream_primed(const ofarn_ctx *c, int w, int h)
 int ofarn_stream_next_device(ofarn_ctx *c, const uint8_t *d_gray, int w, int h, float *d_flow, uint8_t *d_mask, uint8_t *d_v,
                              void *hip_stream)
 {
-    int rc = stream_check(c, w, h);
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    int rc = stream_check(c, w, h, pick_stream(c, hip_stream), true);
     if (rc) return rc;
     if (!d_gray) return fail(OFARN_E_INVALID, "frame is NULL");
     if ((d_mask == nullptr) != (d_v == nullptr)) return fail(OFARN_E_INVALID, "danger mask and v must be given together");
@@ -123,7 +128,8 @@ int ofarn_stream_next_device(ofarn_ctx *c, const uint8_t *d_gray, int w, int h, 
 int ofarn_stream_next_device_bgr(ofarn_ctx *c, const uint8_t *d_bgr, int w, int h, float *d_flow, uint8_t *d_mask, uint8_t *d_v,
                                  void *hip_stream)
 {
-    int rc = stream_check(c, w, h);
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    int rc = stream_check(c, w, h, pick_stream(c, hip_stream), true);
     if (rc) return rc;
     if (!d_bgr) return fail(OFARN_E_INVALID, "frame is NULL");
     if ((d_mask == nullptr) != (d_v == nullptr)) return fail(OFARN_E_INVALID, "danger mask and v must be given together");
