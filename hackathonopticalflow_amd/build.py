@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libofarn.so")
-SOURCES = ["kernels_generic.hip", "kernels_fast.hip", "kernels_gauss.hip", "kernels_tile.hip", "kernels_frontend.hip", "kernels_lk.hip", "ofarn_api.hip", "ofarn_api_extras.hip", "ofarn_api_lk.hip", "ofarn_api_stream.hip"]
+SOURCES = ["kernels_generic.hip", "kernels_fast.hip", "kernels_gauss.hip", "kernels_tile.hip", "kernels_frontend.hip", "kernels_lk.hip", "ofarn_api.hip", "ofarn_api_extras.hip", "ofarn_api_lk.hip", "ofarn_api_stream.hip", "ofarn_api_multi.hip"]
 HEADERS = [os.path.join(CSRC, "ofarn_internal.h"), os.path.join(CSRC, "farneback_device.h"), os.path.join(CSRC, "flow_iter_common.h"), os.path.join(CSRC, "ofarn_host.h"), os.path.join(ROOT, "include", "ofarn.h")]
 # -fno-slp-vectorize: the SLP vectoriser turns pairs of f32 operations into v_pk_mul_f32 / v_pk_add_f32,
 # which measured SLOWER than two scalar VALU ops in these VALU-bound kernels (polyexp 2.42 -> 2.00 ms).
@@ -50,7 +50,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str |
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)
     if force or _stale(lib, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", lib] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", lib] + objs + ["-ldl", "-lpthread"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)

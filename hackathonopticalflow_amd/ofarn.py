@@ -127,6 +127,18 @@ ABI = {
     "ofarn_stream_primed": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ofarn_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "ofarn_host_free": (C.c_int, [C.c_void_p]),
+    "ofarn_shard_pairs": (C.c_int, [C.c_int, C.c_int, C.c_int, _ip, _ip]),
+    "ofarn_multi_create": (C.c_int, [C.POINTER(OfarnParams), _ip, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "ofarn_multi_destroy": (None, [C.c_void_p]),
+    "ofarn_multi_device_count": (C.c_int, [C.c_void_p]),
+    "ofarn_multi_calc_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]),
+    "ofarn_multi_calc_batch_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int,
+                                                C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "ofarn_multi_synchronize": (C.c_int, [C.c_void_p]),
+    "ofarn_multi_stream": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "ofarn_multi_context": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "ofarn_multi_info": (C.c_int, [C.c_void_p, _ip, C.POINTER(C.c_ulonglong), _dp]),
     "ofarn_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ofarn_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
 }
@@ -732,6 +744,107 @@ class FarnebackEngine:
 
 def _params_dict(p: OfarnParams):
     return {f: getattr(p, f) for f, _ in OfarnParams._fields_}
+
+
+# ---------------------------------------------------------------------------------------------
+# Several GPUs in one process (C-ABI ofarn_multi_*; the torch.distributed form of the same sharding is distributed.py)
+# ---------------------------------------------------------------------------------------------
+def _share_rccl_with_torch():
+    """One RCCL per process: PyTorch bundles its own librccl.so; load that copy first (if torch is installed) so that the
+    dlopen inside ofarn_multi_create finds it by soname instead of bringing in the system copy next to it."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass
+
+
+def shard_pairs_c(n_pairs, rank, world):
+    """ofarn_shard_pairs: (start, count) of rank's contiguous pair range -- the C twin of distributed.shard_pairs."""
+    s_, c_ = C.c_int(), C.c_int()
+    _check(load_library().ofarn_shard_pairs(int(n_pairs), int(rank), int(world), C.byref(s_), C.byref(c_)))
+    return s_.value, c_.value
+
+
+class MultiGpuEngine:
+    """ofarn_multi: one context + host thread + stream per GPU of this process, pairs sharded in contiguous ranges, ONE RCCL
+    all-gather of the danger maps.  ``devices``: list of HIP device ordinals (or a count)."""
+
+    def __init__(self, devices, max_width, max_height, max_batch_per_device=64, **params):
+        self._lib = load_library()
+        _share_rccl_with_torch()
+        devs = list(range(devices)) if isinstance(devices, int) else [int(d) for d in devices]
+        self.devices = devs
+        self.params = make_params(**params)
+        arr = (C.c_int * len(devs))(*devs)
+        h = C.c_void_p()
+        _check(self._lib.ofarn_multi_create(C.byref(self.params), arr, len(devs), max_width, max_height, max_batch_per_device,
+                                            C.byref(h)))
+        self._h = h
+        _live_engines.add(self)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ofarn_multi_destroy(self._h)
+            self._h = None
+
+    __del__ = FarnebackEngine.__del__
+    __enter__ = FarnebackEngine.__enter__
+    __exit__ = FarnebackEngine.__exit__
+
+    def calc_batch(self, frames, pairs_mode=PAIRS_INDEPENDENT, want_flow=True, want_danger=True):
+        """frames uint8[n_frames,H,W] on the host -> (flow | None, mask | None, v | None) as FarnebackEngine.calc_batch, computed
+        on all devices; mask / v are the all-gathered maps."""
+        frames = np.ascontiguousarray(frames)
+        if frames.dtype != np.uint8 or frames.ndim != 3:
+            raise ValueError("frames must be uint8[n_frames, H, W]")
+        n, h, w = frames.shape
+        n_pairs = max(n - 1 if pairs_mode == PAIRS_CONSECUTIVE else n // 2, 0)
+        flow = np.empty((n_pairs, h, w, 2), np.float32) if want_flow else None
+        P = len(grid_points(w, h, self.params.grid_step)) if want_danger else 0
+        mask = np.zeros((n_pairs, P), np.uint8) if want_danger else None
+        v = np.zeros((n_pairs, P), np.uint8) if want_danger else None
+        vp = lambda a: C.c_void_p(a.ctypes.data) if a is not None else None
+        _check(self._lib.ofarn_multi_calc_batch(self._h, vp(frames), n, w, h, pairs_mode, vp(flow), vp(mask), vp(v)))
+        return flow, mask, v
+
+    def calc_batch_device(self, d_frames, n_pairs, width, height, pairs_mode=PAIRS_INDEPENDENT, d_flow=None, d_mask_all=None,
+                          d_v_all=None):
+        """Per-device lists of torch CUDA tensors (or raw addresses): d_frames[g] / d_flow[g] hold device g's shard, d_mask_all[g]
+        / d_v_all[g] (uint8[n_pairs,P] on device g) receive the gathered maps.  Enqueues; call synchronize()."""
+        G = len(self.devices)
+        P = len(grid_points(width, height, self.params.grid_step))
+        npx = width * height
+
+        def arr(lst, name, dtype, elems):
+            if lst is None:
+                return None
+            if len(lst) != G:
+                raise ValueError(f"{name} needs one entry per device ({G})")
+            out = (C.c_void_p * G)()
+            for g, t in enumerate(lst):
+                p_ = _ptr(t, f"{name}[{g}]", dtype, elems(g))
+                out[g] = p_.value if p_ is not None else None
+            return out
+        cnt = [shard_pairs_c(n_pairs, g, G)[1] for g in range(G)]
+        nf = lambda g: 0 if cnt[g] == 0 else (cnt[g] + 1 if pairs_mode == PAIRS_CONSECUTIVE else 2 * cnt[g])
+        _check(self._lib.ofarn_multi_calc_batch_device(
+            self._h, arr(d_frames, "d_frames", "uint8", lambda g: nf(g) * npx), n_pairs, width, height, pairs_mode,
+            arr(d_flow, "d_flow", "float32", lambda g: cnt[g] * npx * 2), arr(d_mask_all, "d_mask_all", "uint8", lambda g: n_pairs * P),
+            arr(d_v_all, "d_v_all", "uint8", lambda g: n_pairs * P)))
+
+    def synchronize(self):
+        _check(self._lib.ofarn_multi_synchronize(self._h))
+
+    def info(self):
+        ver, calls, ms = C.c_int(), C.c_ulonglong(), C.c_double()
+        _check(self._lib.ofarn_multi_info(self._h, C.byref(ver), C.byref(calls), C.byref(ms)))
+        return {"devices": list(self.devices), "rccl_version": ver.value, "allgather_calls": calls.value, "last_device_ms": ms.value}
 
 
 # ---------------------------------------------------------------------------------------------

@@ -207,6 +207,38 @@ int ofarn_vector_filter(ofarn_ctx *ctx, const float *h_vecs, int n, int w, int h
 int ofarn_vector_filter_device(ofarn_ctx *ctx, const float *d_vecs, int n, int w, int h, uint8_t *d_mask,
                                uint8_t *d_v, int32_t *d_iflow, void *hip_stream);
 
+/* ---- multi-GPU in one process -------------------------------------------------------
+ * The reference processes one pair per loop turn with no state beyond prev_gray (DenseOF.py:519-525), so pairs are independent
+ * units: device g of G owns the contiguous range ofarn_shard_pairs(n_pairs, g, G) and there is no data-path collective.  One
+ * ofarn_ctx, one host thread and one HIP stream per device; the only exchange is ONE all-gather of the per-pair danger maps
+ * (uint8[n_pairs][P] mask and V: 64 x 2304 x 2 B = 295 KB per device for BASELINE config 4) over RCCL, set up with
+ * ncclCommInitAll over the listed devices (librccl is dlopen'ed here, not linked).  Flow fields are not gathered. */
+typedef struct ofarn_multi ofarn_multi;
+/* Contiguous, balanced shard: the first n_pairs % world ranks get one pair more.  Pure arithmetic (no GPU). */
+int ofarn_shard_pairs(int n_pairs, int rank, int world, int *start, int *count);
+/* devices: n_devices distinct HIP device ordinals (NULL = 0 .. n_devices-1); each gets a context for waves of up to
+ * max_batch_per_device pairs. */
+int ofarn_multi_create(const ofarn_params *params, const int *devices, int n_devices, int max_w, int max_h,
+                       int max_batch_per_device, ofarn_multi **out);
+void ofarn_multi_destroy(ofarn_multi *m);
+int ofarn_multi_device_count(const ofarn_multi *m);
+/* Host frames uint8[n_frames][h][w] (pairs as in ofarn_calc_batch); every device uploads and processes its shard.  h_flow
+ * float32[n_pairs][h][w][2] (may be NULL) is filled shard by shard; h_mask / h_v uint8[n_pairs][P] (together, or both NULL) are
+ * the all-gathered maps as device 0 holds them after the collective.  Synchronous.  Replaces: the loop DenseOF.py:491-525 over a
+ * batch of frames + the filter pathfinder_viewer.py:159-176, 204-217, on G GPUs. */
+int ofarn_multi_calc_batch(ofarn_multi *m, const uint8_t *h_frames, int n_frames, int w, int h, int pairs_mode, float *h_flow,
+                           uint8_t *h_mask, uint8_t *h_v);
+/* Device-resident shards: d_frames[g] / d_flow[g] (d_flow or d_flow[g] may be NULL) are device g's frames and flow output for ITS
+ * pairs (ofarn_shard_pairs(n_pairs, g, G)); d_mask_all[g] / d_v_all[g]: uint8[n_pairs][P] on device g, the gathered maps of ALL
+ * pairs in global order, on every device.  Enqueued on the devices' internal streams (ofarn_multi_stream), not synchronised. */
+int ofarn_multi_calc_batch_device(ofarn_multi *m, const uint8_t *const *d_frames, int n_pairs, int w, int h, int pairs_mode,
+                                  float *const *d_flow, uint8_t *const *d_mask_all, uint8_t *const *d_v_all);
+int ofarn_multi_synchronize(ofarn_multi *m);
+void *ofarn_multi_stream(const ofarn_multi *m, int rank);          /* hipStream_t of a rank */
+ofarn_ctx *ofarn_multi_context(const ofarn_multi *m, int rank);    /* its context (profiling, options) */
+/* RCCL version code (ncclGetVersion), ncclAllGather calls issued so far, device ms of the last host-variant call on rank 0 */
+int ofarn_multi_info(const ofarn_multi *m, int *rccl_version, unsigned long long *allgather_calls, double *last_device_ms);
+
 /* Measurement grid of pathfinder_viewer.py:255-267.  Returns P (number of points, x-major order);
  * if h_pts != NULL writes float32[P][2] = (x, y). */
 int ofarn_grid_points(int w, int h, int step, float *h_pts);

@@ -1,0 +1,127 @@
+"""Multi-GPU at the C-ABI (ofarn_multi_*): one process, one context + host thread + stream per device, pairs sharded, ONE RCCL
+all-gather of the danger maps.  The GPU box has one MI355X: the n = 1 leg runs the whole path -- ncclCommInitAll, the
+in-place ncclAllGather inside an RCCL group, the shard arithmetic with world = 1 -- and must equal ofarn_calc_batch bit for bit.
+With more devices visible the same tests run on all of them."""
+import numpy as np
+import pytest
+
+from hackathonopticalflow_amd.synth import translated_pairs, warped_pairs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    import hackathonopticalflow_amd as H
+    H.load_library()
+    return H
+
+
+def _ndev():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("n_pairs,mode", [(6, 0), (5, 0), (7, 1), (1, 0)])
+def test_multi_host_batch_equals_single_context(H, oracle, n_pairs, mode):
+    w, h = 320, 240
+    n_frames = n_pairs + 1 if mode == 1 else 2 * n_pairs
+    frames, _ = translated_pairs(n_frames // 2 + 1, h, w, 5100, max_shift=3)
+    frames = frames[:n_frames]
+    G = max(1, min(_ndev(), 4))
+    with H.MultiGpuEngine(G, w, h, 4, levels=3) as multi, H.FarnebackEngine(w, h, 4, levels=3) as one:
+        flow, mask, v = multi.calc_batch(frames, mode)
+        f1, m1, v1 = one.calc_batch(frames, mode)
+        np.testing.assert_array_equal(flow, f1)
+        np.testing.assert_array_equal(mask, m1)
+        np.testing.assert_array_equal(v, v1)
+        info = multi.info()
+        assert info["allgather_calls"] == 2 * G and info["rccl_version"] > 0 and info["last_device_ms"] > 0
+        # danger maps only, then flow only
+        _, mask2, v2 = multi.calc_batch(frames, mode, want_flow=False)
+        np.testing.assert_array_equal(mask2, m1)
+        np.testing.assert_array_equal(v2, v1)
+        flow3, m3, _ = multi.calc_batch(frames, mode, want_danger=False)
+        assert m3 is None
+        np.testing.assert_array_equal(flow3, f1)
+        assert multi.info()["allgather_calls"] == 4 * G
+    i = n_pairs - 1
+    a, b = (frames[i], frames[i + 1]) if mode == 1 else (frames[2 * i], frames[2 * i + 1])
+    np.testing.assert_array_equal(flow[i], oracle.farneback(a, b, levels=3, box_mode=oracle.BOX_BLOCKED))
+
+
+def test_multi_device_resident_shards(H, oracle):
+    torch = pytest.importorskip("torch")
+    w, h, n_pairs = 200, 150, 5
+    frames, _ = warped_pairs(n_pairs, h, w, 5200)
+    G = max(1, min(_ndev(), 4))
+    P = len(H.grid_points(w, h, 30))
+    d_frames, d_flow, d_m, d_v = [], [], [], []
+    for g in range(G):
+        s, c = H.shard_pairs_c(n_pairs, g, G)
+        dev = torch.device("cuda", g)
+        d_frames.append(torch.from_numpy(frames[2 * s:2 * (s + c)].copy()).to(dev) if c else torch.empty(0, dtype=torch.uint8, device=dev))
+        d_flow.append(torch.empty((c, h, w, 2), dtype=torch.float32, device=dev))
+        d_m.append(torch.zeros((n_pairs, P), dtype=torch.uint8, device=dev))
+        d_v.append(torch.zeros((n_pairs, P), dtype=torch.uint8, device=dev))
+    torch.cuda.synchronize()
+    with H.MultiGpuEngine(G, w, h, 8, levels=2) as multi:
+        multi.calc_batch_device(d_frames, n_pairs, w, h, H.PAIRS_INDEPENDENT, d_flow, d_m, d_v)
+        multi.synchronize()
+        for g in range(G):
+            s, c = H.shard_pairs_c(n_pairs, g, G)
+            got = d_flow[g].cpu().numpy()
+            for i in range(c):
+                ref = oracle.farneback(frames[2 * (s + i)], frames[2 * (s + i) + 1], levels=2, box_mode=oracle.BOX_BLOCKED)
+                np.testing.assert_array_equal(got[i], ref)
+                m_ref, v_ref = oracle.danger_map_numpy(ref, w, h, 30)
+                for q in range(G):                     # every device holds every pair's map after the gather
+                    np.testing.assert_array_equal(d_m[q][s + i].cpu().numpy(), m_ref)
+                    np.testing.assert_array_equal(d_v[q][s + i].cpu().numpy(), v_ref)
+        with pytest.raises(ValueError):
+            multi.calc_batch_device(d_frames[:0], n_pairs, w, h, H.PAIRS_INDEPENDENT, d_flow, d_m, d_v)
+
+
+def test_multi_create_errors(H):
+    with pytest.raises(ValueError):
+        H.MultiGpuEngine([0, 0], 64, 48, 2)                   # one rank per GPU
+    with pytest.raises(ValueError):
+        H.MultiGpuEngine([_ndev()], 64, 48, 2)
+    with pytest.raises(ValueError):
+        H.MultiGpuEngine([], 64, 48, 2)
+    with H.MultiGpuEngine([0], 64, 48, 2) as multi:
+        with pytest.raises(ValueError):
+            multi.calc_batch(np.zeros((2, 100, 100), np.uint8))   # larger than the contexts
+        with pytest.raises(ValueError):
+            multi.calc_batch(np.zeros((3, 48, 64), np.uint8))     # odd number of frames in independent mode
+        f, m, v = multi.calc_batch(np.zeros((0, 48, 64), np.uint8))
+        assert f.shape == (0, 48, 64, 2) and m.shape[0] == 0
+
+
+def test_c_program_stream_and_multi(H, oracle, tmp_path):
+    """examples/c_abi_stream_multi.c, a C99 program with no Python or torch in the process: the frame loop through
+    ofarn_stream_next (pinned output) and the same pairs as a batch through ofarn_multi_calc_batch (RCCL opened by dlopen from a
+    plain C process) give identical flows, and those equal the oracle's."""
+    import os
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host_abi import _build_c_example
+    exe = _build_c_example(tmp_path, "c_abi_stream_multi")
+    w, h, n = 320, 240, 5
+    frames, _ = translated_pairs(3, h, w, 5300, max_shift=3)
+    frames = frames[:n]
+    (tmp_path / "frames.raw").write_bytes(frames.tobytes())
+    r = subprocess.run([exe, str(tmp_path / "frames.raw"), str(w), str(h), str(n), str(tmp_path / "out"), "3", "1"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "identical" in r.stdout and "ncclAllGather calls" in r.stdout
+    fs = np.fromfile(tmp_path / "out.stream.raw", np.float32).reshape(n - 1, h, w, 2)
+    fm = np.fromfile(tmp_path / "out.multi.raw", np.float32).reshape(n - 1, h, w, 2)
+    np.testing.assert_array_equal(fs, fm)
+    P = len(H.grid_points(w, h, 30))
+    mask = np.fromfile(tmp_path / "out.mask.raw", np.uint8).reshape(n - 1, P)
+    for i in range(n - 1):
+        ref = oracle.farneback(frames[i], frames[i + 1], levels=3, box_mode=oracle.BOX_BLOCKED)
+        np.testing.assert_array_equal(fs[i], ref)
+        np.testing.assert_array_equal(mask[i], oracle.danger_map_numpy(ref, w, h, 30)[0])

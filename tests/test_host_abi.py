@@ -123,13 +123,13 @@ def test_product_never_imports_the_oracle():
                 assert "from oracle" not in txt and "import oracle" not in txt and "libofarn_oracle" not in txt, f
 
 
-def _build_c_example(tmp_path):
+def _build_c_example(tmp_path, name="c_abi_pair"):
     import subprocess
     from hackathonopticalflow_amd import build as hb
-    exe = str(tmp_path / "c_abi_pair")
+    exe = str(tmp_path / name)
     libdir = os.path.dirname(hb.LIB)
     cmd = ["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "examples", "c_abi_pair.c"), "-o", exe, "-L" + libdir, "-lofarn", "-Wl,-rpath," + libdir]
+           os.path.join(ROOT, "examples", name + ".c"), "-o", exe, "-L" + libdir, "-lofarn", "-Wl,-rpath," + libdir]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return exe
@@ -140,6 +140,9 @@ def test_c_abi_header_is_plain_c_and_links(tmp_path):
     with -Wall -Wextra -Werror and links with libofarn.so.  Without arguments it prints its usage and exits with 2 (no GPU call)."""
     import subprocess
     exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+    exe = _build_c_example(tmp_path, "c_abi_stream_multi")       # streaming session + multi-GPU entry points from C99
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr
 
@@ -193,3 +196,32 @@ def test_only_tests_bench_and_smoke_touch_the_oracle():
         if re.search(r"^\s*(from\s+oracle\b|import\s+oracle\b)", src, re.M):
             offenders.append(rel)
     assert not offenders, offenders
+
+
+@pytest.mark.parametrize("n,world", [(512, 8), (64, 8), (10, 4), (3, 8), (0, 2), (7, 1), (513, 8)])
+def test_c_shard_arithmetic_matches_the_python_mirror(n, world):
+    """ofarn_shard_pairs (what ofarn_multi_* shards with) == distributed.shard_pairs (what the torch.distributed ranks use):
+    contiguous, balanced, covering."""
+    from hackathonopticalflow_amd import distributed as D
+    spans = [H.shard_pairs_c(n, r, world) for r in range(world)]
+    assert spans == [D.shard_pairs(n, r, world) for r in range(world)]
+    assert sum(c for _, c in spans) == n
+    with pytest.raises(ValueError):
+        H.shard_pairs_c(4, 4, 4)
+
+
+def test_multi_gpu_entry_points_without_a_gpu():
+    """ofarn_multi_create needs devices: without one it fails with a message, no crash, nothing allocated; RCCL is not a
+    link-time dependency of libofarn.so (it is dlopen'ed by ofarn_multi_create)."""
+    import subprocess
+    import torch
+    from hackathonopticalflow_amd import build as hb
+    needed = subprocess.run(["readelf", "-d", hb.LIB], capture_output=True, text=True).stdout
+    assert "rccl" not in needed and "torch" not in needed
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: covered by tests/test_gpu_multi.py")
+    with pytest.raises((RuntimeError, ValueError)):
+        H.MultiGpuEngine([0], 64, 48, 2)
+    lib = H.load_library()
+    assert lib.ofarn_multi_device_count(None) == 0
+    lib.ofarn_multi_destroy(None)
