@@ -752,6 +752,15 @@ void ofarn_destroy(ofarn_ctx *c)
         for (float *p : {ws.tmp, ws.I, ws.R, ws.M, ws.flowA, ws.flowB}) if (p) (void)hipFree(p);
     if (c->st_flow) (void)hipFree(c->st_flow);
     if (c->d_gwin) (void)hipFree(c->d_gwin);
+    {
+        ofarn_ctx::Stream &st = c->stream_state;
+        if (st.copy_stream) { (void)hipStreamSynchronize(st.copy_stream); (void)hipStreamDestroy(st.copy_stream); }
+        for (int i = 0; i < 2; i++) {
+            if (st.ring[i]) (void)hipFree(st.ring[i]);
+            if (st.ev_computed[i]) (void)hipEventDestroy(st.ev_computed[i]);
+            if (st.ev_copied[i]) (void)hipEventDestroy(st.ev_copied[i]);
+        }
+    }
     if (c->stream_state.R) (void)hipFree(c->stream_state.R);
     for (uint8_t *p : {c->stream_state.d_frame, c->stream_state.d_bgr}) if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev_level) if (e) (void)hipEventDestroy(e);

@@ -217,6 +217,84 @@ int ofarn_stream_next_danger(ofarn_ctx *c, const uint8_t *h_gray, int w, int h, 
     return stream_next_host(c, h_gray, 0, w, h, stride, h_flow, h_mask, h_v);
 }
 
+// Pipelined submission: enqueue the turn and return; the flow lands in h_flow asynchronously (copy stream), while the caller
+// already submits the next frame -- whose kernels then run beside this turn's device-to-host transfer (16.6 MB at 1080p, about as
+// long as the kernels themselves).
+int ofarn_stream_submit(ofarn_ctx *c, const uint8_t *h_gray, int w, int h, int stride, float *h_flow)
+{
+    int rc = stream_check(c, w, h);
+    if (rc) return rc;
+    if (!h_gray) return fail(OFARN_E_INVALID, "frame is NULL");
+    if (stride < w) return fail(OFARN_E_INVALID, "stride %d < width %d", stride, w);
+    if (c->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW)
+        return fail(OFARN_E_UNSUPPORTED, "ofarn_stream_submit does not take OPTFLOW_USE_INITIAL_FLOW (the flow buffer is still in flight "
+                    "when the next turn would need it): use ofarn_stream_next");
+    ofarn_ctx::Stream &st = c->stream_state;
+    const bool had = st.have;
+    if (had && !h_flow) return fail(OFARN_E_INVALID, "flow is NULL");
+    const size_t fsz = (size_t)w * h;
+    if ((rc = grow_u8(c, &st.d_frame, &st.frame_cap, fsz, "streaming frame buffer"))) return rc;
+    if (!st.copy_stream) {
+        if (hipStreamCreateWithFlags(&st.copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(OFARN_E_HIP, "stream creation failed");
+        for (int i = 0; i < 2; i++)
+            if (hipEventCreateWithFlags(&st.ev_computed[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&st.ev_copied[i], hipEventDisableTiming) != hipSuccess)
+                return fail(OFARN_E_HIP, "event creation failed");
+    }
+    if (fsz * 2 > st.ring_cap) {
+        HIP_TRY(hipStreamSynchronize(st.copy_stream));            // a transfer may still read the old buffers
+        for (int i = 0; i < 2; i++) {
+            if (st.ring[i]) { (void)hipFree(st.ring[i]); c->ws_bytes -= st.ring_cap * sizeof(float) + 256; st.ring[i] = nullptr; }
+            st.copied_valid[i] = false;
+        }
+        st.ring_cap = 0;
+        for (int i = 0; i < 2; i++) {
+            if (hipMalloc((void **)&st.ring[i], fsz * 2 * sizeof(float) + 256) != hipSuccess) {
+                (void)hipGetLastError();
+                st.ring[i] = nullptr;
+                return fail(OFARN_E_NOMEM, "flow ring buffer of %zu bytes does not fit", fsz * 2 * sizeof(float));
+            }
+            c->ws_bytes += fsz * 2 * sizeof(float) + 256;
+        }
+        st.ring_cap = fsz * 2;
+    }
+    hipStream_t s = c->stream;
+    if ((rc = begin_call(c, s))) return rc;
+    const int slot = (int)(st.submits & 1);
+    // the transfer of the turn before last read ring[slot]: the kernels that overwrite it wait for that transfer
+    if (st.copied_valid[slot]) HIP_TRY(hipStreamWaitEvent(s, st.ev_copied[slot], 0));
+    if (stride == w) HIP_TRY(hipMemcpyAsync(st.d_frame, h_gray, fsz, hipMemcpyHostToDevice, s));
+    else HIP_TRY(hipMemcpy2DAsync(st.d_frame, w, h_gray, stride, w, h, hipMemcpyHostToDevice, s));
+    const int turn = stream_turn(c, s, st.d_frame, w, h, st.ring[slot], nullptr, nullptr);
+    if (turn < 0) { (void)end_call(c, s); return turn; }
+    if (turn == OFARN_OK) {
+        HIP_TRY(hipEventRecord(st.ev_computed[slot], s));
+        HIP_TRY(hipStreamWaitEvent(st.copy_stream, st.ev_computed[slot], 0));
+        HIP_TRY(hipMemcpyAsync(h_flow, st.ring[slot], fsz * 2 * sizeof(float), hipMemcpyDeviceToHost, st.copy_stream));
+        HIP_TRY(hipEventRecord(st.ev_copied[slot], st.copy_stream));
+        st.copied_valid[slot] = true;
+        st.submits++;
+    }
+    rc = end_call(c, s);
+    return rc ? rc : turn;
+}
+
+int ofarn_stream_wait(ofarn_ctx *c, int leave_in_flight)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    if (leave_in_flight != 0 && leave_in_flight != 1) return fail(OFARN_E_INVALID, "leave_in_flight must be 0 or 1");
+    HIP_TRY(hipSetDevice(c->device));
+    ofarn_ctx::Stream &st = c->stream_state;
+    if (leave_in_flight == 1) {
+        // everything but the most recent turn: the turn before it used the other slot
+        if (st.submits >= 2 && st.copied_valid[st.submits & 1]) HIP_TRY(hipEventSynchronize(st.ev_copied[st.submits & 1]));
+        return OFARN_OK;
+    }
+    if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
+    if (st.copy_stream) HIP_TRY(hipStreamSynchronize(st.copy_stream));
+    return OFARN_OK;
+}
+
 int ofarn_host_alloc(size_t bytes, void **out)
 {
     if (!out) return fail(OFARN_E_INVALID, "out is NULL");

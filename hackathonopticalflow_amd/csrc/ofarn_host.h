@@ -120,6 +120,14 @@ struct ofarn_ctx {
         uint8_t *d_bgr = nullptr;
         size_t frame_cap = 0, bgr_cap = 0;
         unsigned long long turns = 0;
+        // pipelined submission (ofarn_stream_submit / ofarn_stream_wait): two device flow buffers used in turn, a copy stream whose
+        // device-to-host transfer of turn t runs beside the kernels of turn t+1
+        float *ring[2] = {nullptr, nullptr};
+        size_t ring_cap = 0;            // floats, each
+        hipStream_t copy_stream = nullptr;
+        hipEvent_t ev_computed[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+        bool copied_valid[2] = {false, false};
+        unsigned long long submits = 0;
     } stream_state;
     int stream_overlap = 1;             // streaming turn: stages A + B on an internal stream beside the iteration chain (run_wave)
     hipEvent_t ev_level[32] = {nullptr};

@@ -123,6 +123,8 @@ ABI = {
                                            C.c_void_p]),
     "ofarn_stream_next_device_bgr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p]),
+    "ofarn_stream_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ofarn_stream_wait": (C.c_int, [C.c_void_p, C.c_int]),
     "ofarn_stream_reset": (C.c_int, [C.c_void_p]),
     "ofarn_stream_primed": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ofarn_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -485,6 +487,25 @@ class FarnebackEngine:
         if rc < 0:
             _raise(rc)
         return rc == OFARN_OK
+
+    def stream_submit(self, frame, flow) -> bool:
+        """Pipelined turn: enqueue and return (ofarn_stream_submit).  `frame` uint8[H,W] C-contiguous rows, `flow` a float32[H,W,2]
+        C-contiguous array (pinned_empty() for a truly asynchronous transfer) that is complete after stream_wait().  The caller
+        keeps both arrays alive and untouched until then.  Returns False for the priming call."""
+        a = _as_gray(frame, "frame")
+        h, w = a.shape
+        if a.strides[1] != 1 or a.strides[0] < w:
+            raise ValueError("frame rows must be contiguous")
+        if not (isinstance(flow, np.ndarray) and flow.dtype == np.float32 and flow.shape == (h, w, 2) and flow.flags.c_contiguous):
+            raise ValueError(f"flow must be a C-contiguous float32[{h},{w},2] array")
+        rc = self._lib.ofarn_stream_submit(self._h, C.c_void_p(a.ctypes.data), w, h, a.strides[0], C.c_void_p(flow.ctypes.data))
+        if rc < 0:
+            _raise(rc)
+        return rc == OFARN_OK
+
+    def stream_wait(self, leave_in_flight=0):
+        """Waits for the submitted turns: all of them (0) or all but the most recent one (1)."""
+        _check(self._lib.ofarn_stream_wait(self._h, int(leave_in_flight)))
 
     def stream_reset(self):
         _check(self._lib.ofarn_stream_reset(self._h))
@@ -859,12 +880,17 @@ class FlowStream:
     valid until the call AFTER the next one (``copy=True`` returns private copies instead).  A change of frame size or
     ``reset()`` starts a new session."""
 
-    def __init__(self, device=0, copy=False, **params):
-        self._params, self._device, self._copy = params, device, copy
+    def __init__(self, device=0, copy=False, pipelined=False, **params):
+        """pipelined=True trades one frame of latency for throughput: next(frame t) submits turn t and returns the flow of turn
+        t-1 (None for the first TWO frames), so the kernels of turn t run beside the device-to-host transfer of turn t-1;
+        flush() returns the last flow.  Arrays stay valid until the call after next, as in the synchronous mode."""
+        self._params, self._device, self._copy, self._pipelined = params, device, copy, pipelined
         self._eng = None
         self._shape = None
         self._bufs = [None, None]
         self._turn = 0
+        self._pending = None        # pipelined: (buffer, frame) of the turn in flight
+        self._k = 0
 
     def _engine(self, h, w):
         if self._eng is None or self._shape != (h, w):
@@ -872,7 +898,8 @@ class FlowStream:
                 self._eng.close()
             self._eng = FarnebackEngine(w, h, 1, self._device, **self._params)
             self._shape = (h, w)
-            self._bufs = [pinned_empty((h, w, 2)), pinned_empty((h, w, 2))]
+            self._bufs = [pinned_empty((h, w, 2)) for _ in range(3 if self._pipelined else 2)]
+            self._pending = None
         return self._eng
 
     def next(self, frame, want_danger=False):
@@ -881,6 +908,20 @@ class FlowStream:
             raise ValueError(f"frame must be uint8[H,W] or uint8[H,W,3], got shape {a.shape}")
         h, w = a.shape[:2]
         eng = self._engine(h, w)
+        if self._pipelined:
+            if want_danger or a.ndim != 2:
+                raise ValueError("the pipelined mode takes gray frames and returns flows only")
+            a = np.ascontiguousarray(a)
+            buf = self._bufs[self._k]
+            prev = self._pending
+            enq = eng.stream_submit(a, buf)
+            self._pending = (buf, a) if enq else None        # the frame array is kept alive while its upload may be pending
+            if enq:
+                self._k = (self._k + 1) % 3
+            if prev is None:
+                return None
+            eng.stream_wait(1 if enq else 0)
+            return prev[0].copy() if self._copy else prev[0]
         buf = self._bufs[self._turn & 1]
         if eng.params.flags & OPTFLOW_USE_INITIAL_FLOW and self._turn > 1:
             buf[...] = self._bufs[(self._turn - 1) & 1]          # temporal warm start: the previous pair's flow
@@ -898,8 +939,19 @@ class FlowStream:
 
     __call__ = next
 
+    def flush(self):
+        """Pipelined mode: waits for the turn in flight and returns its flow (None if there is none)."""
+        if self._pending is None or self._eng is None:
+            return None
+        self._eng.stream_wait(0)
+        out, self._pending = self._pending[0], None
+        return out.copy() if self._copy else out
+
     def reset(self):
         if self._eng is not None:
+            if self._pending is not None:
+                self._eng.stream_wait(0)
+                self._pending = None
             self._eng.stream_reset()
         self._turn = 0
 
@@ -909,6 +961,9 @@ class FlowStream:
 
     def close(self):
         if self._eng is not None:
+            if self._pending is not None:
+                self._eng.stream_wait(0)
+                self._pending = None
             self._eng.close()
             self._eng = None
         self._bufs = [None, None]

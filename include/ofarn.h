@@ -132,6 +132,16 @@ int ofarn_stream_next_device(ofarn_ctx *ctx, const uint8_t *d_gray, int w, int h
                              uint8_t *d_v, void *hip_stream);
 int ofarn_stream_next_device_bgr(ofarn_ctx *ctx, const uint8_t *d_bgr, int w, int h, float *d_flow, uint8_t *d_mask,
                                  uint8_t *d_v, void *hip_stream);
+/* Pipelined form for throughput: ofarn_stream_submit enqueues the turn (upload, kernels, transfer of the flow into h_flow on a copy
+ * stream) and returns without waiting; the caller submits the next frame at once, whose kernels then run BESIDE this turn's
+ * device-to-host transfer (at 1080p the 16.6 MB of flow take about as long over PCIe as the kernels).  h_flow of a turn is complete
+ * when ofarn_stream_wait returns for it (leave_in_flight = 0: everything submitted so far; 1: everything but the most recent
+ * turn, which keeps running -- the steady state of a pipelined loop); until then it must stay allocated and untouched --
+ * page-locked memory (ofarn_host_alloc) makes the transfer truly asynchronous.  h_gray must stay valid until the NEXT
+ * ofarn_stream_submit / ofarn_stream_wait on this context returns.  Return values as ofarn_stream_next.  Not with
+ * OPTFLOW_USE_INITIAL_FLOW (OFARN_E_UNSUPPORTED). */
+int ofarn_stream_submit(ofarn_ctx *ctx, const uint8_t *h_gray, int w, int h, int stride, float *h_flow);
+int ofarn_stream_wait(ofarn_ctx *ctx, int leave_in_flight);
 /* Forgets the held frame: the next call primes again (a cut in the video, a seek: DenseOF.py:476-481 re-reads prev_gray). */
 int ofarn_stream_reset(ofarn_ctx *ctx);
 /* 1 if the session holds a frame of this size (the next ofarn_stream_next* call will produce a flow), else 0. */

@@ -280,3 +280,42 @@ def test_c_abi_stream_return_codes(H):
         assert lib.ofarn_stream_reset(ctx) == 0 and lib.ofarn_stream_primed(ctx, w, h) == 0
     finally:
         lib.ofarn_destroy(ctx)
+
+
+def test_pipelined_stream(H, oracle):
+    """ofarn_stream_submit / ofarn_stream_wait: turn t is enqueued and the call returns; its flow arrives while turn t+1 runs.
+    FlowStream(pipelined=True).next(frame t) returns the flow of turn t-1; flush() the last one.  Same bits as the pair call."""
+    w, h = 320, 240
+    fr = video(7, h, w, 41)
+    want = [oracle.farneback(fr[i], fr[i + 1], levels=3, box_mode=oracle.BOX_BLOCKED) for i in range(6)]
+    with H.FlowStream(levels=3, pipelined=True) as st:
+        got = [st.next(f) for f in fr]
+        assert got[0] is None and got[1] is None
+        last = st.flush()
+        assert st.flush() is None
+        for i in range(5):
+            np.testing.assert_array_equal(got[i + 2], want[i], err_msg=f"turn {i}")
+        np.testing.assert_array_equal(last, want[5])
+        # reset in the middle of a pipeline: the turn in flight is completed, the session starts over
+        assert st.next(fr[0]) is None
+        assert st.next(fr[1]) is None
+        st.reset()
+        assert st.next(fr[3]) is None and st.next(fr[4]) is None
+        np.testing.assert_array_equal(st.flush(), want[3])
+    # engine level, pageable and pinned outputs, partial waits
+    with H.FarnebackEngine(w, h, 1, levels=3) as eng:
+        outs = [H.pinned_empty((h, w, 2)), np.empty((h, w, 2), np.float32), H.pinned_empty((h, w, 2))]
+        assert eng.stream_submit(fr[0], outs[0]) is False
+        assert eng.stream_submit(fr[1], outs[0]) is True
+        assert eng.stream_submit(fr[2], outs[1]) is True
+        eng.stream_wait(1)
+        np.testing.assert_array_equal(outs[0], want[0])
+        assert eng.stream_submit(fr[3], outs[2]) is True
+        eng.stream_wait(0)
+        np.testing.assert_array_equal(outs[1], want[1])
+        np.testing.assert_array_equal(outs[2], want[2])
+        # the synchronous call continues the same session
+        np.testing.assert_array_equal(eng.stream_next(fr[4]), want[3])
+    with H.FarnebackEngine(w, h, 1, levels=3, flags=4) as eng:
+        with pytest.raises(NotImplementedError):
+            eng.stream_submit(fr[0], np.empty((h, w, 2), np.float32))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turns the output of tools/profile_round.sh (gpurun_out/prof_<tag>/) into the files kept under profiles/:
 
-    python tools/pmc_report.py gpurun_out/prof_r02 r02
+    python tools/pmc_report.py gpurun_out/prof_r03 r03 [W H batch key levels iterations]      (defaults 1920 1080 512 1080p_L5_I3 5 3)
 
   profiles/<tag>_kernel_stats.csv          rocprofv3 --kernel-trace --stats summary of the bench command (ofarn kernels)
   profiles/<tag>_kernel_stats_by_grid.csv  the same trace split per kernel, grid (= pyramid level) and stream
@@ -17,6 +17,10 @@ import os
 import sys
 
 root, tag = sys.argv[1], sys.argv[2]
+W, H, BATCH = (int(x) for x in (sys.argv[3:6] if len(sys.argv) > 5 else (1920, 1080, 512)))
+KEY = sys.argv[6] if len(sys.argv) > 6 else "1080p_L5_I3"
+LEVELS, ITERS = (int(x) for x in (sys.argv[7:9] if len(sys.argv) > 8 else (5, 3)))
+KCMD = f"python3 tools/kbench.py --w {W} --h {H} --levels {LEVELS} --iterations {ITERS} --batch {BATCH} --reps 1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
 
@@ -65,8 +69,8 @@ for f in glob.glob(root + "/pmc_*/**/*counter_collection.csv", recursive=True):
             continue
         cnt[(short(k), r.get("Grid_Size", ""))][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(f"{P}/{tag}_pmc_counters.txt", "w") as o:
-    o.write("# rocprofv3 --pmc <counters> -- python3 tools/kbench.py --levels 5 --batch 256 --reps 1   (one pass per counter group, no trace\n"
-            "# domains; MI355X; one wave of 256 pairs 1920x1080).  Mean counter value per dispatch; kernel@grid threads.\n")
+    o.write(f"# rocprofv3 --pmc <counters> -- {KCMD}   (one pass per counter group, no trace\n"
+            f"# domains; MI355X; one wave of {BATCH} pairs {W}x{H}).  Mean counter value per dispatch; kernel@grid threads.\n")
     for k in sorted(cnt):
         o.write(f"{k[0]}@{k[1]}\n")
         for c, v in sorted(cnt[k].items()):
@@ -83,13 +87,12 @@ def biggest(prefix):
     return max(ks, key=lambda k: int(k[1] or 0)) if ks else None
 
 
-W, H = 1920, 1080
-traffic = {"_provenance": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes (no trace domains) -- python3 tools/kbench.py "
-                          "--levels 5 --batch 256 --reps 1; MI355X, one wave of 256 pairs 1920x1080.  Correction per MI355X_MICROARCH.md "
+traffic = {"_provenance": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes (no trace domains) -- " + KCMD +
+                          f"; MI355X, one wave of {BATCH} pairs {W}x{H}.  Correction per MI355X_MICROARCH.md "
                           "(HBM section): on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads, so reads are doubled; "
                           "WRITE_SIZE is exact.  Per-kernel means: profiles/" + tag + "_pmc_counters.txt (KiB per dispatch)."}
 with open(f"{P}/{tag}_pmc_derived.txt", "w") as o:
-    for prefix, stage, units, alg in (("k_flow_iter<7, 2>", "flow_iter", 256 * W * H, 96.0), ("k_polyexp_march<5, 1>", "polyexp", 512 * W * H, 24.0)):
+    for prefix, stage, units, alg in (("k_flow_iter<7, 2>", "flow_iter", BATCH * W * H, 56.0), ("k_polyexp_march<5, 1>", "polyexp", 2 * BATCH * W * H, 24.0)):
         k = biggest(prefix)
         if not k:
             continue
@@ -140,15 +143,17 @@ for k, cs in cnt.items():
         tot_w += sum(cs["WRITE_SIZE"]) * 1024
 if tot_f:
     passes = 2      # kbench runs the pass once untimed and once timed; both are in the counter file
-    traffic["pipeline_hbm_bytes_per_pair"] = round((2 * tot_f + tot_w) / passes / 256)
-    traffic["pipeline_hbm_bytes_note"] = ("sum over all kernels of one pass of 256 pairs of (2 x FETCH_SIZE + WRITE_SIZE) / 256; "
-                                          "algorithmic (SURVEY 8(d)): 1003.4 MB per pair")
+    traffic["pipeline_hbm_bytes_per_pair"] = round((2 * tot_f + tot_w) / passes / BATCH)
+    traffic["pipeline_hbm_bytes_note"] = (f"sum over all kernels of one pass of {BATCH} pairs of (2 x FETCH_SIZE + WRITE_SIZE) / {BATCH}; "
+                                          "algorithmic (SURVEY 8(d)): 1003.4 MB per pair at 1080p L5 I3, 6154.1 MB at 4K L6 I5")
 if len(traffic) > 1:
     old = {}
     try:
         old = json.load(open(f"{P}/pmc_traffic.json"))
     except Exception:
         pass
-    old.update(traffic)
+    if "flow_iter" in old:        # round-2 layout (flat, one wave of 256 pairs at 1080p): keep it under its own key
+        old = {"1080p_L5_I3_round2_wave256": old}
+    old[KEY] = traffic            # one entry per bench config key (bench.py CONFIGS[...]["key"])
     json.dump(old, open(f"{P}/pmc_traffic.json", "w"), indent=2)
 print(open(f"{P}/{tag}_pmc_derived.txt").read())
