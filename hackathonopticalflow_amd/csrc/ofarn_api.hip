@@ -759,6 +759,8 @@ void ofarn_destroy(ofarn_ctx *c)
             if (st.ring[i]) (void)hipFree(st.ring[i]);
             if (st.ev_computed[i]) (void)hipEventDestroy(st.ev_computed[i]);
             if (st.ev_copied[i]) (void)hipEventDestroy(st.ev_copied[i]);
+            if (st.ev_uploaded[i]) (void)hipEventDestroy(st.ev_uploaded[i]);
+            if (st.h_stage[i]) (void)hipHostFree(st.h_stage[i]);
         }
     }
     if (c->stream_state.R) (void)hipFree(c->stream_state.R);

@@ -238,7 +238,8 @@ int ofarn_stream_submit(ofarn_ctx *c, const uint8_t *h_gray, int w, int h, int s
         if (hipStreamCreateWithFlags(&st.copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(OFARN_E_HIP, "stream creation failed");
         for (int i = 0; i < 2; i++)
             if (hipEventCreateWithFlags(&st.ev_computed[i], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&st.ev_copied[i], hipEventDisableTiming) != hipSuccess)
+                hipEventCreateWithFlags(&st.ev_copied[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&st.ev_uploaded[i], hipEventDisableTiming) != hipSuccess)
                 return fail(OFARN_E_HIP, "event creation failed");
     }
     if (fsz * 2 > st.ring_cap) {
@@ -263,8 +264,42 @@ int ofarn_stream_submit(ofarn_ctx *c, const uint8_t *h_gray, int w, int h, int s
     const int slot = (int)(st.submits & 1);
     // the transfer of the turn before last read ring[slot]: the kernels that overwrite it wait for that transfer
     if (st.copied_valid[slot]) HIP_TRY(hipStreamWaitEvent(s, st.ev_copied[slot], 0));
-    if (stride == w) HIP_TRY(hipMemcpyAsync(st.d_frame, h_gray, fsz, hipMemcpyHostToDevice, s));
-    else HIP_TRY(hipMemcpy2DAsync(st.d_frame, w, h_gray, stride, w, h, hipMemcpyHostToDevice, s));
+    {
+        // a frame in pageable memory goes through one of two page-locked staging buffers (a host copy of w x h bytes): the upload is
+        // then truly asynchronous, the call does not wait for the previous turn's kernels, and the caller's array is free again
+        // when the call returns; a frame that already is page-locked is uploaded from where it lies
+        hipPointerAttribute_t at;
+        const bool pinned = hipPointerGetAttributes(&at, h_gray) == hipSuccess && at.type == hipMemoryTypeHost;
+        if (!pinned) (void)hipGetLastError();
+        const uint8_t *src = h_gray;
+        int sstride = stride;
+        int k = -1;
+        if (!pinned) {
+            k = (int)(st.stages++ & 1);
+            if (fsz > st.stage_cap) {
+                for (int i = 0; i < 2; i++) {
+                    if (st.uploaded_valid[i]) { HIP_TRY(hipEventSynchronize(st.ev_uploaded[i])); st.uploaded_valid[i] = false; }
+                    if (st.h_stage[i]) { (void)hipHostFree(st.h_stage[i]); st.h_stage[i] = nullptr; }
+                }
+                st.stage_cap = 0;
+                for (int i = 0; i < 2; i++)
+                    if (hipHostMalloc((void **)&st.h_stage[i], fsz, hipHostMallocDefault) != hipSuccess) {
+                        (void)hipGetLastError();
+                        st.h_stage[i] = nullptr;
+                        (void)end_call(c, s);
+                        return fail(OFARN_E_NOMEM, "page-locked frame staging of %zu bytes could not be allocated", fsz);
+                    }
+                st.stage_cap = fsz;
+            }
+            if (st.uploaded_valid[k]) HIP_TRY(hipEventSynchronize(st.ev_uploaded[k]));     // its previous upload (two turns ago) is long done
+            for (int y = 0; y < h; y++) memcpy(st.h_stage[k] + (size_t)y * w, h_gray + (size_t)y * stride, (size_t)w);
+            src = st.h_stage[k];
+            sstride = w;
+        }
+        if (sstride == w) HIP_TRY(hipMemcpyAsync(st.d_frame, src, fsz, hipMemcpyHostToDevice, s));
+        else HIP_TRY(hipMemcpy2DAsync(st.d_frame, w, src, sstride, w, h, hipMemcpyHostToDevice, s));
+        if (k >= 0) { HIP_TRY(hipEventRecord(st.ev_uploaded[k], s)); st.uploaded_valid[k] = true; }
+    }
     const int turn = stream_turn(c, s, st.d_frame, w, h, st.ring[slot], nullptr, nullptr);
     if (turn < 0) { (void)end_call(c, s); return turn; }
     if (turn == OFARN_OK) {

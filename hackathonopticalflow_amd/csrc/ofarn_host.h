@@ -128,6 +128,13 @@ struct ofarn_ctx {
         hipEvent_t ev_computed[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
         bool copied_valid[2] = {false, false};
         unsigned long long submits = 0;
+        // page-locked staging of the submitted frames: an asynchronous upload straight from pageable memory would make the
+        // host wait for the stream (the previous turn's kernels) inside the submit call
+        uint8_t *h_stage[2] = {nullptr, nullptr};
+        size_t stage_cap = 0;
+        hipEvent_t ev_uploaded[2] = {nullptr, nullptr};
+        bool uploaded_valid[2] = {false, false};
+        unsigned long long stages = 0;
     } stream_state;
     int stream_overlap = 1;             // streaming turn: stages A + B on an internal stream beside the iteration chain (run_wave)
     hipEvent_t ev_level[32] = {nullptr};

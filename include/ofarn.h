@@ -137,8 +137,10 @@ int ofarn_stream_next_device_bgr(ofarn_ctx *ctx, const uint8_t *d_bgr, int w, in
  * device-to-host transfer (at 1080p the 16.6 MB of flow take about as long over PCIe as the kernels).  h_flow of a turn is complete
  * when ofarn_stream_wait returns for it (leave_in_flight = 0: everything submitted so far; 1: everything but the most recent
  * turn, which keeps running -- the steady state of a pipelined loop); until then it must stay allocated and untouched --
- * page-locked memory (ofarn_host_alloc) makes the transfer truly asynchronous.  h_gray must stay valid until the NEXT
- * ofarn_stream_submit / ofarn_stream_wait on this context returns.  Return values as ofarn_stream_next.  Not with
+ * page-locked memory (ofarn_host_alloc) makes the transfer truly asynchronous.  h_gray in pageable memory is copied into a
+ * page-locked staging buffer by the call and is free again when it returns; a page-locked h_gray is uploaded from where it lies and
+ * must stay untouched until the NEXT ofarn_stream_submit / ofarn_stream_wait on this context returns.  Return values as
+ * ofarn_stream_next.  Not with
  * OPTFLOW_USE_INITIAL_FLOW (OFARN_E_UNSUPPORTED). */
 int ofarn_stream_submit(ofarn_ctx *ctx, const uint8_t *h_gray, int w, int h, int stride, float *h_flow);
 int ofarn_stream_wait(ofarn_ctx *ctx, int leave_in_flight);

@@ -288,7 +288,7 @@ def test_pipelined_stream(H, oracle):
     w, h = 320, 240
     fr = video(7, h, w, 41)
     want = [oracle.farneback(fr[i], fr[i + 1], levels=3, box_mode=oracle.BOX_BLOCKED) for i in range(6)]
-    with H.FlowStream(levels=3, pipelined=True) as st:
+    with H.FlowStream(levels=3, pipelined=True, copy=True) as st:
         got = [st.next(f) for f in fr]
         assert got[0] is None and got[1] is None
         last = st.flush()
@@ -296,7 +296,18 @@ def test_pipelined_stream(H, oracle):
         for i in range(5):
             np.testing.assert_array_equal(got[i + 2], want[i], err_msg=f"turn {i}")
         np.testing.assert_array_equal(last, want[5])
+    with H.FlowStream(levels=3, pipelined=True) as st:      # without copies: an array stays valid until the call after next
+        assert st.next(fr[0]) is None and st.next(fr[1]) is None
+        f0 = st.next(fr[2])
+        np.testing.assert_array_equal(f0, want[0])
+        f1 = st.next(fr[3])
+        np.testing.assert_array_equal(f0, want[0])
+        np.testing.assert_array_equal(f1, want[1])
+        f2 = st.next(fr[4])
+        np.testing.assert_array_equal(f1, want[1])
+        np.testing.assert_array_equal(f2, want[2])
         # reset in the middle of a pipeline: the turn in flight is completed, the session starts over
+        st.reset()
         assert st.next(fr[0]) is None
         assert st.next(fr[1]) is None
         st.reset()

@@ -40,6 +40,33 @@ def main():
             ts.append((time.perf_counter() - t0) * 1e3)
             dev.append(eng.last_device_ms)
         print(f"zero_copy={zc}: wall median {np.median(ts):.4f} ms (min {min(ts):.4f}), device {np.median(dev):.4f} ms")
+    # pipelined submission: where does the host spend its time?
+    outs = [ofa.pinned_empty((a.h, a.w, 2)) for _ in range(3)]
+    pin = [ofa.pinned_empty((a.h, a.w), np.uint8) for _ in range(4)]
+    for p_, f_ in zip(pin, fr):
+        p_[...] = f_
+    for name, src in (("pageable frames", fr), ("pinned frames", pin)):
+        eng.stream_reset()
+        eng.stream_submit(src[0], outs[0])
+        for i in range(4):
+            eng.stream_submit(src[(i + 1) % 4], outs[i % 3])
+        eng.stream_wait(0)
+        ts_sub, ts_wait = [], []
+        t_all = time.perf_counter()
+        for i in range(a.reps):
+            t0 = time.perf_counter()
+            eng.stream_submit(src[(i + 1) % 4], outs[i % 3])
+            t1 = time.perf_counter()
+            eng.stream_wait(1)
+            t2 = time.perf_counter()
+            ts_sub.append((t1 - t0) * 1e3)
+            ts_wait.append((t2 - t1) * 1e3)
+        eng.stream_wait(0)
+        t_all = (time.perf_counter() - t_all) / a.reps * 1e3
+        print(f"pipelined, {name}: {t_all:.4f} ms per frame; submit call {np.median(ts_sub):.4f} ms, wait(1) {np.median(ts_wait):.4f} ms")
+    eng.stream_reset()
+    eng.stream_next(fr[0])
+    eng.stream_next(fr[1], out)
     eng.profile_enable(True)
     for i in range(a.reps):
         eng.stream_next(fr[(i + 2) % 4], out)
