@@ -76,13 +76,32 @@ def run(frames_bgr, device=0, step=30, want_hsv=True):
                 mean_flow=d_flow.mean(dim=(1, 2)).cpu().numpy())
 
 
+def run_loop(frames_bgr, device=0, step=30):
+    """The same dense results produced the way the reference's loop produces them -- one decoded BGR frame per turn
+    (DenseOF.py:491-525), host arrays in and out -- through FlowStream: the previous frame stays on the device, each turn
+    uploads one frame.  Returns (flows float32[n-1,H,W,2], masks uint8[n-1,P], vs uint8[n-1,P])."""
+    import hackathonopticalflow_amd as ofa
+    flows, masks, vs = [], [], []
+    with ofa.FlowStream(device=device, copy=True) as stream:                  # DenseOF.py defaults
+        for img in frames_bgr:
+            flow = stream.next(img)                                             # cvtColor + Farneback; None for the first frame
+            if flow is None:
+                continue
+            mask, v = ofa.danger_map(flow, step, device=device)                 # pathfinder_viewer.py:159-176, 204-217
+            flows.append(flow); masks.append(mask); vs.append(v)
+    return np.stack(flows), np.stack(masks), np.stack(vs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=9)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     a = ap.parse_args()
-    out = run(synthetic_video(a.frames, a.height, a.width))
+    video = synthetic_video(a.frames, a.height, a.width)
+    out = run(video)
+    _, loop_masks, _ = run_loop(video)
+    print("frame loop (FlowStream) and batch danger masks identical:", bool((loop_masks == out["dense_mask"]).all()))
     for i in range(a.frames - 1):
         print(f"pair {i}: mean dense flow {out['mean_flow'][i].round(3)}  danger points dense {int(out['dense_mask'][i].sum())}"
               f" / LK {int(out['lk_mask'][i].sum())} of {len(out['points'])}  LK tracked {int(out['lk_status'][i].sum())}")

@@ -748,6 +748,11 @@ def test_headless_viewer_example(H):
     assert np.abs(out["mean_flow"] - (2, 1)).max() < 0.3          # whole-frame mean: the borders pull it down a little
     assert out["lk_status"].all()
     assert np.abs(np.median(out["lines"][:, :, 1] - out["lines"][:, :, 0], axis=1) - (-2, -1)).max() <= 1
+    # the frame loop (one BGR frame per turn through FlowStream) gives what the device-resident batch gave
+    flows, masks, vs = mod.run_loop(frames)
+    np.testing.assert_array_equal(masks, out["dense_mask"])
+    np.testing.assert_array_equal(vs, out["dense_v"])
+    assert np.abs(flows.mean(axis=(1, 2)) - out["mean_flow"]).max() < 1e-4
 
 
 def test_lk_batch_points_per_pair_and_forward_direction(H, oracle):
