@@ -34,6 +34,12 @@ for i in range(N):
     ref = O.farneback(a, b, box_mode=O.BOX_BLOCKED, init_flow=init, **kw)
     with H.FarnebackEngine(w, h, 1, **kw) as eng:
         got = eng.calc(a, b, None if init is None else init.copy())
+        # the same pair as a streaming session (round 3): prime with a, then one turn with b -- must equal the pair call
+        assert eng.stream_next(a, None if init is None else init.copy()) is None
+        got_s = eng.stream_next(b, None if init is None else init.copy())
+    if not np.array_equal(got_s, got):
+        bad += 1
+        print("STREAM MISMATCH", w, h, kw, float(np.abs(got_s - got).max()), flush=True)
     if not np.array_equal(got, ref):
         bad += 1
         print("MISMATCH", w, h, kw, os.environ["OFARN_DIRECT_MIN_FRAMES"], float(np.abs(got - ref).max()), flush=True)
