@@ -56,6 +56,34 @@ void launch_bgr2gray(hipStream_t s, const uint8_t *bgr, uint8_t *gray, size_t np
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_push_host (EXPERIMENT, off by default: ofarn_set_option "push_blocks"): device buffer -> page-locked host memory mapped into the
+// device's address space, by a grid of chosen size.  The idea: on this platform a 16.6 MB device-to-host hipMemcpyAsync runs as the
+// runtime's blit kernel (__amd_rocclr_copyBuffer, ~0.30 ms) whose grid fills the chip, and in a rocprofv3 timeline of the pipelined frame
+// loop the next turn's kernels start only when it has drained; PCIe needs ~100 KB in flight, so a few dozen blocks should saturate it and
+// leave the CUs to the next turn.  Measured (profiles/r03_streamprof.txt): 0.79 ms per frame with 8, 16, 32, 64 or 256 blocks against
+// 0.57 ms with hipMemcpyAsync -- the push itself takes ~0.6 ms whatever its size when the next turn's chain of small kernels runs
+// beside it.  Kept for the record; the copy path is the default.  16 B per lane, four loads in flight per lane.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_push_host(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
+void launch_push_host(hipStream_t s, const float *src, float *dst_mapped, size_t nfloats, int blocks)
+{
+    if (nfloats == 0) return;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_push_host, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4 *>(src),
+                       reinterpret_cast<float4 *>(dst_mapped), nfloats / 4);
+}
+
+// ---------------------------------------------------------------------------------------------
 // resize(INTER_AREA) of 2-channel float flow, shrinking, followed by `flow *= scale`.
 // One thread per output element (pair, dy, dx, channel), accumulating in OpenCV's order:
 //   general (ResizeArea_Invoker): per source row of the cell  buf = 0; buf = buf + S*alpha (x table order);

@@ -794,6 +794,7 @@ int ofarn_set_option(ofarn_ctx *c, const char *name, int value)
     else if (n == "single_stream") c->dual = value == 0;
     else if (n == "stream_zero_copy") c->stream_zero_copy = value != 0;
     else if (n == "stream_overlap") c->stream_overlap = value != 0;
+    else if (n == "push_blocks") c->push_blocks = value < 0 ? 0 : value;
     else if (n == "debug_fail_wave") c->debug_fail_wave = value;
     else return fail(OFARN_E_INVALID, "unknown option '%s'", name);
     return OFARN_OK;

@@ -305,7 +305,18 @@ int ofarn_stream_submit(ofarn_ctx *c, const uint8_t *h_gray, int w, int h, int s
     if (turn == OFARN_OK) {
         HIP_TRY(hipEventRecord(st.ev_computed[slot], s));
         HIP_TRY(hipStreamWaitEvent(st.copy_stream, st.ev_computed[slot], 0));
-        HIP_TRY(hipMemcpyAsync(h_flow, st.ring[slot], fsz * 2 * sizeof(float), hipMemcpyDeviceToHost, st.copy_stream));
+        // page-locked destination: pushed by a small kernel that leaves the CUs to the next turn (see k_push_host); else a plain copy
+        void *mapped = nullptr;
+        if (c->push_blocks > 0 && (fsz * 2) % 4 == 0 && ((uintptr_t)h_flow & 15) == 0) {
+            hipPointerAttribute_t at;
+            if (!(hipPointerGetAttributes(&at, h_flow) == hipSuccess && at.type == hipMemoryTypeHost &&
+                  hipHostGetDevicePointer(&mapped, h_flow, 0) == hipSuccess && mapped)) {
+                (void)hipGetLastError();
+                mapped = nullptr;
+            }
+        }
+        if (mapped) launch_push_host(st.copy_stream, st.ring[slot], static_cast<float *>(mapped), fsz * 2, c->push_blocks);
+        else HIP_TRY(hipMemcpyAsync(h_flow, st.ring[slot], fsz * 2 * sizeof(float), hipMemcpyDeviceToHost, st.copy_stream));
         HIP_TRY(hipEventRecord(st.ev_copied[slot], st.copy_stream));
         st.copied_valid[slot] = true;
         st.submits++;

@@ -138,6 +138,8 @@ struct ofarn_ctx {
     } stream_state;
     int stream_overlap = 1;             // streaming turn: stages A + B on an internal stream beside the iteration chain (run_wave)
     hipEvent_t ev_level[32] = {nullptr};
+    int push_blocks = 0;                // ofarn_stream_submit: > 0 pushes a finished flow field to pinned host memory with a kernel of that many
+                                        // blocks instead of hipMemcpyAsync ("push_blocks"; measured slower at every size, kept as an experiment)
     int stream_zero_copy = 1;           // ofarn_stream_next: let the last kernel write a pinned flow buffer itself (OFARN_STREAM_ZERO_COPY=0: copy)
     // host-API staging (lazy)
     uint8_t *st_frames = nullptr;

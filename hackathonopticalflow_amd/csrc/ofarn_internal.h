@@ -116,6 +116,8 @@ void launch_grid_filter(hipStream_t s, const float *flow, int w, int h, int npai
 // ---- front end / back end of the call (kernels_frontend.hip) ----
 // cv2.cvtColor(COLOR_BGR2GRAY) on n pixels of packed BGR; coefficients and shift from color_rgb.simd.hpp.
 void launch_bgr2gray(hipStream_t s, const uint8_t *bgr, uint8_t *gray, size_t npx_total, int cb, int cg, int cr, int shift);
+// device buffer -> page-locked, device-mapped host memory with a grid of `blocks` blocks (nfloats a multiple of 4, both 16-byte aligned)
+void launch_push_host(hipStream_t s, const float *src, float *dst_mapped, size_t nfloats, int blocks);
 // resize(INTER_AREA) tables (device pointers), see k_resize_area
 struct AreaTabHost {
     int *xstart = nullptr, *xsi = nullptr, *ystart = nullptr, *ysi = nullptr;

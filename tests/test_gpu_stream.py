@@ -202,7 +202,7 @@ def test_drop_in_reuses_the_previous_frame(H, oracle, monkeypatch):
     # a copy of the right frame is another object: correct, no reuse
     np.testing.assert_array_equal(H.calculate_optical_flow(fr[3].copy(), fr[4], levels=2), ref(fr[3], fr[4]))
     assert len(resets) == 2
-    # the held frame overwritten in place: noticed (strided fingerprint), correct
+    # the held frame overwritten in place: noticed (checksum of every 8th row), correct
     keep = fr[4].copy()
     fr[4][:] = fr[0]
     np.testing.assert_array_equal(H.calculate_optical_flow(fr[4], fr[5], levels=2), ref(fr[0], fr[5]))

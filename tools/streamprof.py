@@ -45,7 +45,9 @@ def main():
     pin = [ofa.pinned_empty((a.h, a.w), np.uint8) for _ in range(4)]
     for p_, f_ in zip(pin, fr):
         p_[...] = f_
-    for name, src in (("pageable frames", fr), ("pinned frames", pin)):
+    for name, src, pb in (("pageable frames", fr, 0), ("pinned frames", pin, 0), ("pinned frames, push kernel of 8 blocks", pin, 8),
+                          ("pinned frames, push kernel of 32 blocks", pin, 32), ("pinned frames, push kernel of 256 blocks", pin, 256)):
+        eng.set_option("push_blocks", pb)
         eng.stream_reset()
         eng.stream_submit(src[0], outs[0])
         for i in range(4):
@@ -64,6 +66,7 @@ def main():
         eng.stream_wait(0)
         t_all = (time.perf_counter() - t_all) / a.reps * 1e3
         print(f"pipelined, {name}: {t_all:.4f} ms per frame; submit call {np.median(ts_sub):.4f} ms, wait(1) {np.median(ts_wait):.4f} ms")
+    eng.set_option("push_blocks", 0)
     eng.stream_reset()
     eng.stream_next(fr[0])
     eng.stream_next(fr[1], out)
