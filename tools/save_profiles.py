@@ -1,40 +1,46 @@
 #!/usr/bin/env python3
-"""Copies one bench run + its rocprofv3 kernel trace from gpurun_out/ into profiles/ (the files the judge reads).
+"""Copies what a round measured on the GPU box from gpurun_out/ (scratch) into profiles/ (tracked; what the judge reads).
 
-    python tools/save_profiles.py gpurun_out/bench19.json gpurun_out/bench19.err gpurun_out/prof_v9
+    python tools/save_profiles.py r03
+
+  gpurun_out/evidence_<tag>/*          (tools/collect_evidence.sh: every number DESIGN.md section 7 quotes besides the headline, each
+                                        file starting with its command line)                      -> profiles/<tag>_<name>
+  gpurun_out/prof_<tag>/, prof_<tag>_4k (tools/profile_round.sh: kernel trace + PMC passes)         -> via tools/pmc_report.py:
+                                        profiles/<tag>_kernel_stats*.csv, <tag>_pmc_*.txt, pmc_traffic.json, <tag>_trace_bench.json
+  gpurun_out/<tag>_bench_final.json/.err (python bench.py --steps 20 --warmup 5 --prof-table)      -> profiles/<tag>_bench_final.json,
+                                        profiles/<tag>_bench_final_stage_table.txt
 """
-import collections
-import csv
+import glob
+import os
+import shutil
+import subprocess
 import sys
 
-bench_json, bench_err, prof_dir = sys.argv[1:4]
-open("profiles/r01_bench_final.json", "w").write(open(bench_json).read())
-open("profiles/r01_bench_final_stage_table.txt", "w").write(
-    "".join(l for l in open(bench_err) if "amdgpu.ids" not in l))
-rows = list(csv.DictReader(open(prof_dir + "/runc_kernel_stats.csv")))
-with open("profiles/r01_kernel_stats.csv", "w") as o:
-    o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-two-stream (MI355X, final round-1 build); ofarn kernels only\n")
-    w = csv.DictWriter(o, fieldnames=rows[0].keys())
-    w.writeheader()
-    for r in rows:
-        if "ofarn::" in r["Name"]:
-            w.writerow(r)
-acc = collections.defaultdict(list)
-for r in csv.DictReader(open(prof_dir + "/runc_kernel_trace.csv")):
-    n = r["Kernel_Name"]
-    if "ofarn::" not in n:
-        continue
-    short = n.split("(")[0].replace("void ", "")
-    acc[(short, r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"], r["Stream_Id"])].append(
-        int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-with open("profiles/r01_kernel_stats_by_grid.csv", "w") as o:
-    o.write("# Derived from the kernel trace of the same rocprofv3 --kernel-trace --stats run as r01_kernel_stats.csv.\n"
-            "# Split per kernel, grid (= pyramid level) and stream.  bench.py measures roofline.kernel_avg_ms with HIP events over its timed\n"
-            "# region, in which per-kernel profiling keeps all waves on ONE stream (kernels do not overlap): compare with the rows of\n"
-            "# stream 0 (the caller's: torch's default stream).  The warm-up step runs with per-kernel timing off on two internal streams (ids 2 and 3), where\n"
-            "# kernels of two waves overlap and each one's duration is about doubled.\n")
-    o.write("kernel,grid_x,grid_y,grid_z,stream_id,calls,avg_ns,total_ns\n")
-    for k in sorted(acc, key=lambda k: -sum(acc[k])):
-        v = acc[k]
-        o.write(f"\"{k[0]}\",{k[1]},{k[2]},{k[3]},{k[4]},{len(v)},{sum(v) / len(v):.0f},{sum(v)}\n")
-print(open("profiles/r01_bench_final.json").read()[:120])
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+n = 0
+for f in sorted(glob.glob(os.path.join(G, f"evidence_{tag}", "*"))):
+    shutil.copy(f, os.path.join(P, f"{tag}_{os.path.basename(f)}"))
+    n += 1
+for src, dst in ((f"{tag}_bench_final.json", f"{tag}_bench_final.json"),):
+    if os.path.exists(os.path.join(G, src)):
+        shutil.copy(os.path.join(G, src), os.path.join(P, dst))
+        n += 1
+err = os.path.join(G, f"{tag}_bench_final.err")
+if os.path.exists(err):
+    open(os.path.join(P, f"{tag}_bench_final_stage_table.txt"), "w").write(
+        "".join(line for line in open(err) if "amdgpu.ids" not in line))
+    n += 1
+if os.path.isdir(os.path.join(G, f"prof_{tag}")):
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_report.py"), os.path.join(G, f"prof_{tag}"), tag], check=True,
+                   stdout=subprocess.DEVNULL)
+    tb = os.path.join(G, f"prof_{tag}", "trace_bench.json")
+    if os.path.exists(tb):
+        shutil.copy(tb, os.path.join(P, f"{tag}_trace_bench.json"))
+    n += 1
+if os.path.isdir(os.path.join(G, f"prof_{tag}_4k")):
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_report.py"), os.path.join(G, f"prof_{tag}_4k"), f"{tag}_4k", "3840", "2160", "64",
+                    "4k_L6_I5", "6", "5"], check=True, stdout=subprocess.DEVNULL)
+    n += 1
+print(f"{n} item(s) copied into profiles/ for {tag}")
