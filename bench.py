@@ -335,11 +335,12 @@ def bench_stream(args, cfg, params):
     t_all = time.perf_counter() - t_all
     # the same loop pipelined (FlowStream(pipelined=True): next(frame t) returns the flow of turn t-1 while turn t runs)
     stp = ofa.FlowStream(pipelined=True, **params)
-    for i in range(args.warmup + 2):
+    wp = max(args.warmup + 2, 40)      # the first few dozen turns of a process run slower (pinned buffers first touched, clocks): steady state
+    for i in range(wp):
         stp.next(frames_in[i % nuniq])
     t_p = time.perf_counter()
     for i in range(args.steps):
-        stp.next(frames_in[(i + args.warmup + 2) % nuniq])
+        stp.next(frames_in[(i + wp) % nuniq])
     stp.flush()
     t_p = (time.perf_counter() - t_p) / args.steps * 1e3
     stp.close()
@@ -417,7 +418,7 @@ def main():
     if args.steps is None:
         args.steps = 20 if args.config == 2 else 5
     if args.warmup is None:
-        args.warmup = 5 if args.config == 2 else 2
+        args.warmup = (40 if args.stream else 5) if args.config == 2 else 2
     if args.steps < 1 or args.warmup < 0 or args.wave < 1 or (args.batch is not None and args.batch < 1):
         raise SystemExit("--steps, --batch and --wave must be >= 1, --warmup >= 0")
 

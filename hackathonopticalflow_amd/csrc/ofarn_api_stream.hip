@@ -235,7 +235,16 @@ int ofarn_stream_submit(ofarn_ctx *c, const uint8_t *h_gray, int w, int h, int s
     const size_t fsz = (size_t)w * h;
     if ((rc = grow_u8(c, &st.d_frame, &st.frame_cap, fsz, "streaming frame buffer"))) return rc;
     if (!st.copy_stream) {
-        if (hipStreamCreateWithFlags(&st.copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(OFARN_E_HIP, "stream creation failed");
+        // Lowest stream priority: streams of one priority share a small pool of hardware queues, and which streams end up on one
+        // queue depends on how many the process created before (measured: the pipelined loop takes 0.58, 0.69 or 0.88 ms per
+        // frame depending on that alone).  A priority of its own gives the transfer its own queue whatever else exists, and lets
+        // the next turn's kernels go first when both have workgroups to place.
+        int prio_least = 0, prio_greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { (void)hipGetLastError(); prio_least = 0; }
+        if (hipStreamCreateWithPriority(&st.copy_stream, hipStreamNonBlocking, prio_least) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipStreamCreateWithFlags(&st.copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(OFARN_E_HIP, "stream creation failed");
+        }
         for (int i = 0; i < 2; i++)
             if (hipEventCreateWithFlags(&st.ev_computed[i], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&st.ev_copied[i], hipEventDisableTiming) != hipSuccess ||
@@ -300,7 +309,14 @@ int ofarn_stream_submit(ofarn_ctx *c, const uint8_t *h_gray, int w, int h, int s
         else HIP_TRY(hipMemcpy2DAsync(st.d_frame, w, src, sstride, w, h, hipMemcpyHostToDevice, s));
         if (k >= 0) { HIP_TRY(hipEventRecord(st.ev_uploaded[k], s)); st.uploaded_valid[k] = true; }
     }
+    // No side stream for stages A + B here: the previous turn's transfer is running on the copy stream, and a THIRD hardware queue in
+    // play means that -- depending on which queues the driver happens to put on one pipe -- the level builds can sit behind the
+    // 0.3 ms blit kernel while the iteration chain waits for them (measured: 1.0-1.6 ms per frame instead of 0.58 for two of eight
+    // stream-creation histories).  The overlap is worth 20 us; not here.
+    const int keep_overlap = c->stream_overlap;
+    c->stream_overlap = 0;
     const int turn = stream_turn(c, s, st.d_frame, w, h, st.ring[slot], nullptr, nullptr);
+    c->stream_overlap = keep_overlap;
     if (turn < 0) { (void)end_call(c, s); return turn; }
     if (turn == OFARN_OK) {
         HIP_TRY(hipEventRecord(st.ev_computed[slot], s));

@@ -66,6 +66,15 @@ def main():
         eng.stream_wait(0)
         t_all = (time.perf_counter() - t_all) / a.reps * 1e3
         print(f"pipelined, {name}: {t_all:.4f} ms per frame; submit call {np.median(ts_sub):.4f} ms, wait(1) {np.median(ts_wait):.4f} ms")
+    # the same loop through the Python class (what bench.py --config 2 --stream reports as pipelined_ms_per_frame)
+    with ofa.FlowStream(levels=a.levels, pipelined=True) as stp:
+        for i in range(6):
+            stp.next(fr[i % 4])
+        t_all = time.perf_counter()
+        for i in range(a.reps):
+            stp.next(fr[(i + 2) % 4])
+        stp.flush()
+        print(f"pipelined, FlowStream(pipelined=True), pageable frames: {(time.perf_counter() - t_all) / a.reps * 1e3:.4f} ms per frame")
     eng.set_option("push_blocks", 0)
     eng.stream_reset()
     eng.stream_next(fr[0])
