@@ -675,7 +675,7 @@ void ofarn_default_params(ofarn_params *p)
 
 const char *ofarn_last_error(void) { return g_err.c_str(); }
 
-const char *ofarn_version(void) { return "ofarn 0.2.0 gfx950 (HIP, fp-contract=off)"; }
+const char *ofarn_version(void) { return "ofarn 0.3.0 gfx950 (HIP, fp-contract=off)"; }
 
 int ofarn_create(const ofarn_params *params, int device, int max_w, int max_h, int max_batch, ofarn_ctx **out)
 {

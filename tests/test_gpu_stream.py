@@ -330,3 +330,23 @@ def test_pipelined_stream(H, oracle):
     with H.FarnebackEngine(w, h, 1, levels=3, flags=4) as eng:
         with pytest.raises(NotImplementedError):
             eng.stream_submit(fr[0], np.empty((h, w, 2), np.float32))
+
+
+def test_stream_4k_levels6_iterations5(H):
+    """BASELINE config 5's shape through the frame loop: 3840x2160, levels 6, iterations 5 (seven scales, 495 MB of session state):
+    synchronous and pipelined turns equal the pair call."""
+    w, h = 3840, 2160
+    a, b, _ = translated_pair(h, w, 5001)
+    c = np.ascontiguousarray(np.roll(b, (3, -5), axis=(0, 1)))
+    kw = dict(levels=6, iterations=5)
+    with H.FarnebackEngine(w, h, 1, **kw) as eng:
+        want = [eng.calc(a, b), eng.calc(b, c)]
+    with H.FlowStream(**kw) as st:
+        assert st.next(a) is None
+        np.testing.assert_array_equal(st.next(b), want[0])
+        np.testing.assert_array_equal(st.next(c), want[1])
+    with H.FlowStream(pipelined=True, copy=True, **kw) as st:
+        got = [st.next(f) for f in (a, b, c)] + [st.flush()]
+        assert got[0] is None and got[1] is None
+        np.testing.assert_array_equal(got[2], want[0])
+        np.testing.assert_array_equal(got[3], want[1])
