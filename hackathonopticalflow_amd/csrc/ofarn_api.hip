@@ -762,10 +762,12 @@ void ofarn_destroy(ofarn_ctx *c)
     {
         ofarn_ctx::Stream &st = c->stream_state;
         if (st.copy_stream) { (void)hipStreamSynchronize(st.copy_stream); (void)hipStreamDestroy(st.copy_stream); }
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < ofarn_ctx::Stream::kRing; i++) {
             if (st.ring[i]) (void)hipFree(st.ring[i]);
             if (st.ev_computed[i]) (void)hipEventDestroy(st.ev_computed[i]);
             if (st.ev_copied[i]) (void)hipEventDestroy(st.ev_copied[i]);
+        }
+        for (int i = 0; i < 2; i++) {
             if (st.ev_uploaded[i]) (void)hipEventDestroy(st.ev_uploaded[i]);
             if (st.h_stage[i]) (void)hipHostFree(st.h_stage[i]);
         }

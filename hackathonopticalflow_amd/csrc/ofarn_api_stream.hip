@@ -245,20 +245,22 @@ int ofarn_stream_submit(ofarn_ctx *c, const uint8_t *h_gray, int w, int h, int s
             (void)hipGetLastError();
             if (hipStreamCreateWithFlags(&st.copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(OFARN_E_HIP, "stream creation failed");
         }
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < ofarn_ctx::Stream::kRing; i++)
             if (hipEventCreateWithFlags(&st.ev_computed[i], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&st.ev_copied[i], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&st.ev_uploaded[i], hipEventDisableTiming) != hipSuccess)
+                hipEventCreateWithFlags(&st.ev_copied[i], hipEventDisableTiming) != hipSuccess)
+                return fail(OFARN_E_HIP, "event creation failed");
+        for (int i = 0; i < 2; i++)
+            if (hipEventCreateWithFlags(&st.ev_uploaded[i], hipEventDisableTiming) != hipSuccess)
                 return fail(OFARN_E_HIP, "event creation failed");
     }
     if (fsz * 2 > st.ring_cap) {
         HIP_TRY(hipStreamSynchronize(st.copy_stream));            // a transfer may still read the old buffers
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < ofarn_ctx::Stream::kRing; i++) {
             if (st.ring[i]) { (void)hipFree(st.ring[i]); c->ws_bytes -= st.ring_cap * sizeof(float) + 256; st.ring[i] = nullptr; }
             st.copied_valid[i] = false;
         }
         st.ring_cap = 0;
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < ofarn_ctx::Stream::kRing; i++) {
             if (hipMalloc((void **)&st.ring[i], fsz * 2 * sizeof(float) + 256) != hipSuccess) {
                 (void)hipGetLastError();
                 st.ring[i] = nullptr;
@@ -270,8 +272,8 @@ int ofarn_stream_submit(ofarn_ctx *c, const uint8_t *h_gray, int w, int h, int s
     }
     hipStream_t s = c->stream;
     if ((rc = begin_call(c, s))) return rc;
-    const int slot = (int)(st.submits & 1);
-    // the transfer of the turn before last read ring[slot]: the kernels that overwrite it wait for that transfer
+    const int slot = (int)(st.submits % ofarn_ctx::Stream::kRing);
+    // the transfer of the turn kRing turns ago read ring[slot]: the kernels that overwrite it wait for that transfer
     if (st.copied_valid[slot]) HIP_TRY(hipStreamWaitEvent(s, st.ev_copied[slot], 0));
     {
         // a frame in pageable memory goes through one of two page-locked staging buffers (a host copy of w x h bytes): the upload is
@@ -344,12 +346,17 @@ int ofarn_stream_submit(ofarn_ctx *c, const uint8_t *h_gray, int w, int h, int s
 int ofarn_stream_wait(ofarn_ctx *c, int leave_in_flight)
 {
     if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
-    if (leave_in_flight != 0 && leave_in_flight != 1) return fail(OFARN_E_INVALID, "leave_in_flight must be 0 or 1");
+    constexpr int K = ofarn_ctx::Stream::kRing;
+    if (leave_in_flight < 0 || leave_in_flight >= K) return fail(OFARN_E_INVALID, "leave_in_flight must be in [0, %d]", K - 1);
     HIP_TRY(hipSetDevice(c->device));
     ofarn_ctx::Stream &st = c->stream_state;
-    if (leave_in_flight == 1) {
-        // everything but the most recent turn: the turn before it used the other slot
-        if (st.submits >= 2 && st.copied_valid[st.submits & 1]) HIP_TRY(hipEventSynchronize(st.ev_copied[st.submits & 1]));
+    if (leave_in_flight > 0) {
+        // everything but the `leave_in_flight` most recent turns: turn n (0-based) used slot n % K; transfers complete in order, so
+        // waiting for the newest turn that must be complete is enough
+        if (st.submits > (unsigned long long)leave_in_flight) {
+            const int slot = (int)((st.submits - 1 - leave_in_flight) % K);
+            if (st.copied_valid[slot]) HIP_TRY(hipEventSynchronize(st.ev_copied[slot]));
+        }
         return OFARN_OK;
     }
     if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));

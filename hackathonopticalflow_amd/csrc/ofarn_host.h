@@ -122,11 +122,12 @@ struct ofarn_ctx {
         unsigned long long turns = 0;
         // pipelined submission (ofarn_stream_submit / ofarn_stream_wait): two device flow buffers used in turn, a copy stream whose
         // device-to-host transfer of turn t runs beside the kernels of turn t+1
-        float *ring[2] = {nullptr, nullptr};
+        static constexpr int kRing = 3;  // turns whose flow can be on its way to the host at once + the one being computed
+        float *ring[kRing] = {nullptr, nullptr, nullptr};
         size_t ring_cap = 0;            // floats, each
         hipStream_t copy_stream = nullptr;
-        hipEvent_t ev_computed[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
-        bool copied_valid[2] = {false, false};
+        hipEvent_t ev_computed[kRing] = {nullptr, nullptr, nullptr}, ev_copied[kRing] = {nullptr, nullptr, nullptr};
+        bool copied_valid[kRing] = {false, false, false};
         unsigned long long submits = 0;
         // page-locked staging of the submitted frames: an asynchronous upload straight from pageable memory would make the
         // host wait for the stream (the previous turn's kernels) inside the submit call

@@ -881,15 +881,17 @@ class FlowStream:
     ``reset()`` starts a new session."""
 
     def __init__(self, device=0, copy=False, pipelined=False, **params):
-        """pipelined=True trades one frame of latency for throughput: next(frame t) submits turn t and returns the flow of turn
+        """pipelined=True (or 1) trades one frame of latency for throughput: next(frame t) submits turn t and returns the flow of turn
         t-1 (None for the first TWO frames), so the kernels of turn t run beside the device-to-host transfer of turn t-1;
-        flush() returns the last flow.  Arrays stay valid until the call after next, as in the synchronous mode."""
-        self._params, self._device, self._copy, self._pipelined = params, device, copy, pipelined
+        pipelined=2 keeps two turns in flight (returns turn t-2).  flush() returns the oldest flow still in flight (call it until
+        it returns None).  Arrays stay valid until the call after next, as in the synchronous mode."""
+        self._params, self._device, self._copy = params, device, copy
+        self._pipelined = min(int(pipelined), 2)      # turns in flight: True / 1 -> next(t) returns turn t-1; 2 -> turn t-2
         self._eng = None
         self._shape = None
         self._bufs = [None, None]
         self._turn = 0
-        self._pending = None        # pipelined: (buffer, frame) of the turn in flight
+        self._pending = []          # pipelined: (buffer, frame) of the turns in flight, oldest first
         self._k = 0
 
     def _engine(self, h, w):
@@ -898,8 +900,8 @@ class FlowStream:
                 self._eng.close()
             self._eng = FarnebackEngine(w, h, 1, self._device, **self._params)
             self._shape = (h, w)
-            self._bufs = [pinned_empty((h, w, 2)) for _ in range(3 if self._pipelined else 2)]
-            self._pending = None
+            self._bufs = [pinned_empty((h, w, 2)) for _ in range(self._pipelined + 2 if self._pipelined else 2)]
+            self._pending = []
         return self._eng
 
     def next(self, frame, want_danger=False):
@@ -913,15 +915,17 @@ class FlowStream:
                 raise ValueError("the pipelined mode takes gray frames and returns flows only")
             a = np.ascontiguousarray(a)
             buf = self._bufs[self._k]
-            prev = self._pending
             enq = eng.stream_submit(a, buf)
-            self._pending = (buf, a) if enq else None        # the frame array is kept alive while its upload may be pending
             if enq:
-                self._k = (self._k + 1) % 3
-            if prev is None:
+                self._pending.append((buf, a))               # the frame array is kept alive while its upload may be pending
+                self._k = (self._k + 1) % len(self._bufs)
+            elif self._pending:                              # a priming call in the middle (size change): drain what is in flight
+                eng.stream_wait(0)
+            if len(self._pending) <= (self._pipelined if enq else 0):
                 return None
-            eng.stream_wait(1 if enq else 0)
-            return prev[0].copy() if self._copy else prev[0]
+            eng.stream_wait(len(self._pending) - 1)
+            out = self._pending.pop(0)[0]
+            return out.copy() if self._copy else out
         buf = self._bufs[self._turn & 1]
         if eng.params.flags & OPTFLOW_USE_INITIAL_FLOW and self._turn > 1:
             buf[...] = self._bufs[(self._turn - 1) & 1]          # temporal warm start: the previous pair's flow
@@ -941,17 +945,17 @@ class FlowStream:
 
     def flush(self):
         """Pipelined mode: waits for the turn in flight and returns its flow (None if there is none)."""
-        if self._pending is None or self._eng is None:
+        if not self._pending or self._eng is None:
             return None
-        self._eng.stream_wait(0)
-        out, self._pending = self._pending[0], None
+        self._eng.stream_wait(len(self._pending) - 1)
+        out = self._pending.pop(0)[0]
         return out.copy() if self._copy else out
 
     def reset(self):
         if self._eng is not None:
-            if self._pending is not None:
+            if self._pending:
                 self._eng.stream_wait(0)
-                self._pending = None
+                self._pending = []
             self._eng.stream_reset()
         self._turn = 0
 
@@ -961,9 +965,9 @@ class FlowStream:
 
     def close(self):
         if self._eng is not None:
-            if self._pending is not None:
+            if self._pending:
                 self._eng.stream_wait(0)
-                self._pending = None
+                self._pending = []
             self._eng.close()
             self._eng = None
         self._bufs = [None, None]

@@ -135,8 +135,8 @@ int ofarn_stream_next_device_bgr(ofarn_ctx *ctx, const uint8_t *d_bgr, int w, in
 /* Pipelined form for throughput: ofarn_stream_submit enqueues the turn (upload, kernels, transfer of the flow into h_flow on a copy
  * stream) and returns without waiting; the caller submits the next frame at once, whose kernels then run BESIDE this turn's
  * device-to-host transfer (at 1080p the 16.6 MB of flow take about as long over PCIe as the kernels).  h_flow of a turn is complete
- * when ofarn_stream_wait returns for it (leave_in_flight = 0: everything submitted so far; 1: everything but the most recent
- * turn, which keeps running -- the steady state of a pipelined loop); until then it must stay allocated and untouched --
+ * when ofarn_stream_wait returns for it (leave_in_flight = 0: everything submitted so far; 1 or 2: everything but the most recent
+ * one or two turns, which keep running -- the steady state of a pipelined loop); until then it must stay allocated and untouched --
  * page-locked memory (ofarn_host_alloc) makes the transfer truly asynchronous.  h_gray in pageable memory is copied into a
  * page-locked staging buffer by the call and is free again when it returns; a page-locked h_gray is uploaded from where it lies and
  * must stay untouched until the NEXT ofarn_stream_submit / ofarn_stream_wait on this context returns.  Return values as

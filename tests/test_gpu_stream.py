@@ -313,6 +313,14 @@ def test_pipelined_stream(H, oracle):
         st.reset()
         assert st.next(fr[3]) is None and st.next(fr[4]) is None
         np.testing.assert_array_equal(st.flush(), want[3])
+    with H.FlowStream(levels=3, pipelined=2, copy=True) as st:      # two turns in flight: next(t) returns turn t-2
+        got = [st.next(f) for f in fr]
+        assert got[0] is None and got[1] is None and got[2] is None
+        for i in range(4):
+            np.testing.assert_array_equal(got[i + 3], want[i], err_msg=f"depth 2, turn {i}")
+        np.testing.assert_array_equal(st.flush(), want[4])
+        np.testing.assert_array_equal(st.flush(), want[5])
+        assert st.flush() is None
     # engine level, pageable and pinned outputs, partial waits
     with H.FarnebackEngine(w, h, 1, levels=3) as eng:
         outs = [H.pinned_empty((h, w, 2)), np.empty((h, w, 2), np.float32), H.pinned_empty((h, w, 2))]

@@ -66,7 +66,29 @@ def main():
         eng.stream_wait(0)
         t_all = (time.perf_counter() - t_all) / a.reps * 1e3
         print(f"pipelined, {name}: {t_all:.4f} ms per frame; submit call {np.median(ts_sub):.4f} ms, wait(1) {np.median(ts_wait):.4f} ms")
+    # two turns in flight
+    outs4 = [ofa.pinned_empty((a.h, a.w, 2)) for _ in range(4)]
+    eng.stream_reset()
+    eng.stream_submit(pin[0], outs4[0])
+    for i in range(6):
+        eng.stream_submit(pin[(i + 1) % 4], outs4[i % 4])
+        eng.stream_wait(2)
+    t_all = time.perf_counter()
+    for i in range(a.reps):
+        eng.stream_submit(pin[(i + 1) % 4], outs4[i % 4])
+        eng.stream_wait(2)
+    eng.stream_wait(0)
+    print(f"pipelined, pinned frames, TWO turns in flight: {(time.perf_counter() - t_all) / a.reps * 1e3:.4f} ms per frame")
     # the same loop through the Python class (what bench.py --config 2 --stream reports as pipelined_ms_per_frame)
+    with ofa.FlowStream(levels=a.levels, pipelined=2) as stp:
+        for i in range(8):
+            stp.next(fr[i % 4])
+        t_all = time.perf_counter()
+        for i in range(a.reps):
+            stp.next(fr[(i + 2) % 4])
+        while stp.flush() is not None:
+            pass
+        print(f"pipelined, FlowStream(pipelined=2), pageable frames: {(time.perf_counter() - t_all) / a.reps * 1e3:.4f} ms per frame")
     with ofa.FlowStream(levels=a.levels, pipelined=True) as stp:
         for i in range(6):
             stp.next(fr[i % 4])
