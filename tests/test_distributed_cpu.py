@@ -107,3 +107,51 @@ def test_bench_starts_its_own_ranks():
     env2 = dict(env, RANK="0", WORLD_SIZE="3", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env2)
     assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr
+
+
+def _ws1_worker(port, q):
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch
+    from hackathonopticalflow_amd import distributed as DD
+    assert DD.init_process_group("gloo") is None                    # world size 1 without force: no group
+    dist = DD.init_process_group("gloo", force=True)                # bench.py --force-dist: a one-rank group still runs the collective
+    P, n = 352, 6
+    rng = np.random.default_rng(5)
+    ok = True
+    g = DD.DangerGather(n, P, "cpu", dist)
+    ptrs = (g.send.data_ptr(), g.recv.data_ptr(), g.mask_all.data_ptr(), g.v_all.data_ptr())
+    ok &= g.even and g.mask_all.data_ptr() == g.recv.data_ptr()     # even shards: the results are views of the receive block
+    for it in range(3):
+        m = torch.from_numpy(rng.integers(0, 2, (n, P)).astype(np.uint8))
+        v = torch.from_numpy(rng.integers(0, 256, (n, P)).astype(np.uint8))
+        ma, va = g(m, v)
+        ok &= bool((ma == m).all()) and bool((va == v).all()) and ma.shape == (n, P)
+        ok &= ptrs == (g.send.data_ptr(), g.recv.data_ptr(), g.mask_all.data_ptr(), g.v_all.data_ptr())   # nothing reallocated
+        ma2, _ = DD.gather_danger_maps(m, v, n, dist)               # the cached gather of the functional form
+        ok &= bool((ma2 == m).all())
+    ok &= g.calls == 3
+    try:
+        g(torch.zeros((n - 1, P), dtype=torch.uint8), torch.zeros((n - 1, P), dtype=torch.uint8))
+        ok = False
+    except ValueError:
+        pass
+    DD.reset_gathers()
+    dist.destroy_process_group()
+    q.put(ok)
+
+
+def test_gather_at_world_size_one_is_allocation_free():
+    """The collective at world size 1 (what `bench.py --gpus 1 --force-dist` runs, there over RCCL on device tensors): buffers
+    allocated once, results are views of the receive block, wrong shard sizes are refused."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_ws1_worker, args=(port, q))
+    p.start()
+    assert q.get(timeout=120) is True
+    p.join(timeout=60)
+    assert p.exitcode == 0

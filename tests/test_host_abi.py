@@ -225,3 +225,29 @@ def test_multi_gpu_entry_points_without_a_gpu():
     lib = H.load_library()
     assert lib.ofarn_multi_device_count(None) == 0
     lib.ofarn_multi_destroy(None)
+
+
+def test_drop_in_frame_reuse_bookkeeping():
+    """The drop-in's reuse rule without a GPU: a slot "holds" a frame only if it is the SAME array object as the last call's `next`
+    and its fingerprint (address, shape, strides, checksum of every 8th row) is unchanged; an in-place change to a sampled row, a
+    copy, a view, a dead reference or a non-array are all "not held"."""
+    slot = ofarn._Slot(eng=None)
+    a = np.random.default_rng(0).integers(0, 256, (120, 160)).astype(np.uint8)
+    assert not slot.holds(a)
+    slot.remember(a)
+    assert slot.holds(a)
+    assert not slot.holds(a.copy()) and not slot.holds(a[:]) and not slot.holds(a.tolist())
+    a[8, 5] ^= 1                          # row 8 is sampled
+    assert not slot.holds(a)
+    a[8, 5] ^= 1
+    assert slot.holds(a)
+    b = a.copy()
+    slot.remember(b)
+    assert slot.holds(b) and not slot.holds(a)
+    del b
+    import gc
+    gc.collect()
+    assert slot.last_ref() is None and not slot.holds(a)
+    slot.remember([1, 2, 3])              # not weak-referenceable: forgotten
+    assert slot.last_ref is None
+    assert ofarn._frame_signature(a) == ofarn._frame_signature(a) != ofarn._frame_signature(a.copy())
