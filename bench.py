@@ -106,11 +106,14 @@ def smooth_base_gpu(torch, hh, ww, seed, device, sigma=4.0):
     k = (k / k.sum())
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    base = torch.randn((1, 1, hh, ww), generator=g, device=device)
-    base = torch.nn.functional.pad(base, (r, r, 0, 0), mode="circular")
-    base = torch.nn.functional.conv2d(base, k.view(1, 1, 1, -1))
-    base = torch.nn.functional.pad(base, (0, 0, r, r), mode="circular")
-    base = torch.nn.functional.conv2d(base, k.view(1, 1, -1, 1))[0, 0]
+    base = torch.randn((hh, ww), generator=g, device=device)
+    # separable circular Gaussian as 2 x 33 shifted multiply-adds (plain elementwise kernels: no MIOpen convolution search, which eight
+    # ranks starting at once would all run against one user database)
+    for dim in (1, 0):
+        acc = torch.zeros_like(base)
+        for i in range(2 * r + 1):
+            acc.add_(torch.roll(base, shifts=r - i, dims=dim), alpha=float(k[i]))
+        base = acc
     lo, hi = base.min(), base.max()
     return (base - lo) * (255.0 / (hi - lo))
 
