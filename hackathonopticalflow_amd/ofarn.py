@@ -373,9 +373,14 @@ class FarnebackEngine:
                                     prev.strides[0], flow.ctypes.data_as(_fp)))
         return flow
 
-    def calc_batch(self, frames, pairs_mode=PAIRS_INDEPENDENT, want_flow=True, want_danger=True, init_flow=None):
+    def calc_batch(self, frames, pairs_mode=PAIRS_INDEPENDENT, want_flow=True, want_danger=True, init_flow=None, pinned=False,
+                   out_flow=None):
         """frames uint8[n_frames,H,W] -> (flow float32[n_pairs,H,W,2] | None, mask u8[n_pairs,P] | None,
-        v u8[n_pairs,P] | None).  With OPTFLOW_USE_INITIAL_FLOW, init_flow float32[n_pairs,H,W,2] is required."""
+        v u8[n_pairs,P] | None).  With OPTFLOW_USE_INITIAL_FLOW, init_flow float32[n_pairs,H,W,2] is required.
+        pinned=True returns the flow in page-locked memory (pinned_empty): the 16.6 MB per 1080p pair then cross PCIe at the
+        link's rate instead of through the runtime's pageable staging; frames given in a pinned_empty() array are uploaded the
+        same way.  out_flow: a C-contiguous float32[n_pairs,H,W,2] array to fill and return instead of a new one (page-locking 1 GB
+        takes longer than transferring it: allocate a pinned_empty() buffer once and pass it to every call)."""
         frames = np.asarray(frames)
         if frames.dtype != np.uint8 or frames.ndim != 3:
             raise ValueError("frames must be uint8[n_frames, H, W]")
@@ -383,11 +388,20 @@ class FarnebackEngine:
         n, h, w = frames.shape
         n_pairs = n - 1 if pairs_mode == PAIRS_CONSECUTIVE else n // 2
         n_pairs = max(n_pairs, 0)
-        flow = np.empty((n_pairs, h, w, 2), np.float32) if want_flow else None
+        alloc = pinned_empty if pinned else np.empty
+        if out_flow is not None:
+            if not (isinstance(out_flow, np.ndarray) and out_flow.dtype == np.float32 and out_flow.shape == (n_pairs, h, w, 2)
+                    and out_flow.flags.c_contiguous and out_flow.flags.writeable):
+                raise ValueError(f"out_flow must be a writable C-contiguous float32 array of shape {(n_pairs, h, w, 2)}")
+            flow, want_flow = out_flow, True
+        else:
+            flow = alloc((n_pairs, h, w, 2), np.float32) if want_flow else None
         if self.params.flags & OPTFLOW_USE_INITIAL_FLOW:
             if init_flow is None or np.shape(init_flow) != (n_pairs, h, w, 2):
                 raise ValueError(f"OPTFLOW_USE_INITIAL_FLOW needs init_flow of shape {(n_pairs, h, w, 2)}")
-            flow = np.array(init_flow, np.float32, order="C")
+            if flow is None:
+                flow = alloc((n_pairs, h, w, 2), np.float32)
+            flow[...] = init_flow
             want_flow = True
         P = len(grid_points(w, h, self.params.grid_step)) if want_danger else 0
         mask = np.zeros((n_pairs, P), np.uint8) if want_danger else None
