@@ -347,6 +347,22 @@ def bench_stream(args, cfg, params):
     stp.flush()
     t_p = (time.perf_counter() - t_p) / args.steps * 1e3
     stp.close()
+    # the same loop returning what the reference DRAWS from the flow (danger map + draw_flow's arrow lines, optionally draw_hsv's
+    # rainbow) instead of the flow field, which stays in HBM: ofarn_stream_next_view
+    view = {}
+    with ofa.FlowStream(**params) as stv:
+        for rb, key in ((False, "view_ms_per_frame"), (True, "view_rainbow_ms_per_frame")):
+            stv.reset()
+            for i in range(12):
+                stv.next_view(frames_in[i % nuniq], rainbow=rb)
+            tv, dv = [], []
+            for i in range(args.steps):
+                t0 = time.perf_counter()
+                stv.next_view(frames_in[(i + 12) % nuniq], rainbow=rb)
+                tv.append((time.perf_counter() - t0) * 1e3)
+                dv.append(stv.last_device_ms)
+            view[key] = round(float(np.median(tv)), 4)
+            view[key.replace("_ms_per_frame", "_device_ms")] = round(float(np.median(dv)), 4)
     last_pair = (frames[(args.steps - 1) % nuniq], frames[args.steps % nuniq])
     plan = ofa.level_plan(W, H, **params)
     alg = algorithmic_bytes_per_pair(W, H, plan, params["iterations"])
@@ -364,6 +380,8 @@ def bench_stream(args, cfg, params):
         "pairs_per_s_wall": round(1e3 / float(np.median(ts)), 1),
         "zero_copy": os.environ.get("OFARN_STREAM_ZERO_COPY", "1") != "0",
         "pipelined_ms_per_frame": round(t_p, 4), "pipelined_pairs_per_s_wall": round(1e3 / t_p, 1),
+        "view": dict(view, note="synchronous turn returning the danger map + arrow lines (and, second pair of figures, the rainbow image) "
+                                "computed from the flow on the device; the float32 flow field stays in HBM"),
         "roofline": {"bound": "latency (dependent launches on grids of a few blocks) + PCIe (16.6 MB of flow per frame)",
                      "achieved": round(alg / (dms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,

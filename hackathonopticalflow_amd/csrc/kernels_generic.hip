@@ -424,12 +424,46 @@ __global__ __launch_bounds__(1024) void k_grid_filter(const float2 *__restrict__
         s_prefix[tid] = 0u;
     }
     if (tid == 0) s_nan = 0;
+    // Up to GF_CACHE points per thread keep their vector and modulus in registers (the default 2304-point grid with 1024 threads:
+    // three): the select passes and the output loop then read nothing from memory again.  The loads of a thread's points are
+    // issued together -- one memory round trip instead of one per point and pass, which is what a single pair's launch consists of
+    // (72 -> ~15 us at 1080p; a batch does not notice).  Denser grids fall back to recomputing from the flow on every pass.
+    constexpr int GF_CACHE = 4;
+    const bool cached = P <= GF_CACHE * nt;
+    float2 dc[GF_CACHE];
+    float mc[GF_CACHE];
+    if (cached) {
+        int2 pc[GF_CACHE];
+#pragma unroll
+        for (int j = 0; j < GF_CACHE; j++) { const int i = tid + j * nt; pc[j] = i < P ? pts[i] : make_int2(0, 0); }
+#pragma unroll
+        for (int j = 0; j < GF_CACHE; j++) {
+            const int i = tid + j * nt;
+            dc[j] = i < P ? (vp ? vp[i] : f[(size_t)pc[j].y * w + pc[j].x]) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < GF_CACHE; j++) mc[j] = grid_modulus(dc[j], pc[j], hw, hh);
+    }
     for (int pass = 0; pass < 4; pass++) {
         const int shift = 24 - 8 * pass;
         for (int i = tid; i < 4 * 256; i += nt) (&s_hist[0][0])[i] = 0u;
         __syncthreads();
         const unsigned himask = pass == 0 ? 0u : 0xFFFFFFFFu << (shift + 8);
         const unsigned p0 = s_prefix[0], p1 = s_prefix[1], p2 = s_prefix[2], p3 = s_prefix[3];
+        if (cached) {
+#pragma unroll
+            for (int j = 0; j < GF_CACHE; j++) {
+                if (tid + j * nt >= P) continue;
+                const float m = mc[j];
+                if (m != m) { if (pass == 0) s_nan = 1; continue; }
+                const unsigned u = __float_as_uint(m);
+                const unsigned hi = u & himask, dg = (u >> shift) & 255u;
+                if (hi == p0) atomicAdd(&s_hist[0][dg], 1u);
+                if (hi == p1) atomicAdd(&s_hist[1][dg], 1u);
+                if (hi == p2) atomicAdd(&s_hist[2][dg], 1u);
+                if (hi == p3) atomicAdd(&s_hist[3][dg], 1u);
+            }
+        } else
         for (int i = tid; i < P; i += nt) {
             const float m = modulus_at(i);
             if (m != m) { if (pass == 0) s_nan = 1; continue; }
@@ -441,16 +475,37 @@ __global__ __launch_bounds__(1024) void k_grid_filter(const float2 *__restrict__
             if (hi == p3) atomicAdd(&s_hist[3][dg], 1u);
         }
         __syncthreads();
-        if (tid < 4) {
-            unsigned r = s_rank[tid], acc = 0;
-            int d = 0;
-            for (; d < 255; d++) {
-                const unsigned cnt = s_hist[tid][d];
-                if (acc + cnt > r) break;
-                acc += cnt;
+        // digit of rank r = the first bin d in [0, 254] whose inclusive count exceeds r, else 255.  One wave per wanted rank: lane l sums
+        // bins 4l .. 4l+3, a wave-wide inclusive scan of those sums locates the lane, the lane locates the bin (a single thread walking
+        // 256 LDS words one after the other took ~12 us per pass -- most of a one-pair launch)
+        if (tid < 256) {
+            const int k = tid >> 6, l = tid & 63;
+            const unsigned r = s_rank[k];
+            const unsigned c0 = s_hist[k][4 * l], c1 = s_hist[k][4 * l + 1], c2 = s_hist[k][4 * l + 2], c3 = s_hist[k][4 * l + 3];
+            const unsigned own = (c0 + c1) + (c2 + c3);
+            unsigned incl = own;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = (unsigned)__shfl_up((int)incl, o, 64);
+                if (l >= o) incl += t;
             }
-            s_rank[tid] = r - acc;
-            s_prefix[tid] |= (unsigned)d << shift;
+            const unsigned excl = incl - own;
+            // exactly one lane has excl <= r < incl if r is below the total; bins 255 never stops the walk (it is the fall-through)
+            int d = -1;
+            unsigned before = 0;
+            if (excl <= r && r < incl) {
+                if (r < excl + c0) { d = 4 * l; before = excl; }
+                else if (r < excl + c0 + c1) { d = 4 * l + 1; before = excl + c0; }
+                else if (r < excl + c0 + c1 + c2) { d = 4 * l + 2; before = excl + c0 + c1; }
+                else { d = 4 * l + 3; before = excl + c0 + c1 + c2; }
+                if (d == 255) before = excl + c0 + c1 + c2;      // same value: the walk would have ended at 255 with acc = everything before it
+            }
+            const unsigned long long found = __ballot(d >= 0);
+            if (found == 0ull && l == 63) { d = 255; before = incl - c3; }      // r beyond the total: d = 255, acc = bins 0 .. 254
+            if (d >= 0) {
+                s_rank[k] = r - before;
+                s_prefix[k] |= (unsigned)d << shift;
+            }
         }
         __syncthreads();
     }
@@ -468,11 +523,19 @@ __global__ __launch_bounds__(1024) void k_grid_filter(const float2 *__restrict__
     }
     __syncthreads();
     const float med = s_thr[0], p99 = s_thr[1];
-    for (int i = tid; i < P; i += nt) {
+    for (int i = tid, j = 0; i < P; i += nt, j++) {
         const int2 p = pts[i];
-        const float2 d = vp ? vp[i] : f[(size_t)p.y * w + p.x];
+        float2 d;
+        float mod;
+        if (cached) {
+            d = dc[0]; mod = mc[0];
+#pragma unroll
+            for (int q = 1; q < GF_CACHE; q++) if (j == q) { d = dc[q]; mod = mc[q]; }
+        } else {
+            d = vp ? vp[i] : f[(size_t)p.y * w + p.x];
+            mod = grid_modulus(d, p, hw, hh);
+        }
         const float x = (float)p.x, y = (float)p.y;
-        const float mod = grid_modulus(d, p, hw, hh);
         // variant 0: pathfinder_viewer.py:173  (median*1.0 < mod) & (mod < P99)
         // variant 1: DenseOF.py:228            mod > median*1.2   (float32 product)
         const bool keep = variant == 1 ? (mod > med * 1.2f) : ((med < mod) && (mod < p99));
@@ -576,7 +639,10 @@ void launch_grid_filter(hipStream_t s, const float *flow, int w, int h, int npai
                         int variant, uint8_t *mask, uint8_t *v, int32_t *iflow, const float *vecs)
 {
     if (npairs <= 0 || P <= 0) return;
-    hipLaunchKernelGGL(k_grid_filter, dim3(npairs), dim3(P >= 4096 ? 1024 : 256), 0, s,
+    // few pairs: the launch is latency bound, so spread a pair's points over 1024 threads (at most 4 cached points each up to P = 4096);
+    // many pairs: 256 threads per pair fill the chip either way
+    const int nt = (P >= 4096 || (npairs <= 64 && P > 256)) ? 1024 : 256;
+    hipLaunchKernelGGL(k_grid_filter, dim3(npairs), dim3(nt), 0, s,
                        reinterpret_cast<const float2 *>(flow), w, h, reinterpret_cast<const int2 *>(d_pts), P,
                        variant, mask, v, iflow, reinterpret_cast<const float2 *>(vecs));
 }

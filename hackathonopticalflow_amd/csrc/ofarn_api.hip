@@ -762,6 +762,7 @@ void ofarn_destroy(ofarn_ctx *c)
     {
         ofarn_ctx::Stream &st = c->stream_state;
         if (st.copy_stream) { (void)hipStreamSynchronize(st.copy_stream); (void)hipStreamDestroy(st.copy_stream); }
+        if (st.h_view) (void)hipHostFree(st.h_view);
         for (int i = 0; i < ofarn_ctx::Stream::kRing; i++) {
             if (st.ring[i]) (void)hipFree(st.ring[i]);
             if (st.ev_computed[i]) (void)hipEventDestroy(st.ev_computed[i]);
@@ -773,7 +774,7 @@ void ofarn_destroy(ofarn_ctx *c)
         }
     }
     if (c->stream_state.R) (void)hipFree(c->stream_state.R);
-    for (uint8_t *p : {c->stream_state.d_frame, c->stream_state.d_bgr}) if (p) (void)hipFree(p);
+    for (uint8_t *p : {c->stream_state.d_frame, c->stream_state.d_bgr, c->stream_state.d_view}) if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev_level) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; i++) {
         if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }

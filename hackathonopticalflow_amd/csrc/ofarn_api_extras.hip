@@ -5,7 +5,7 @@
 using namespace ofarn;
 using namespace ofarn_host;
 
-namespace {
+namespace ofarn_host {
 
 // np.mgrid[step/2:size:step] (DenseOF.py:44): count and float start
 int arrow_axis(int size, int step, double *start)
@@ -15,7 +15,7 @@ int arrow_axis(int size, int step, double *start)
     return n < 0 ? 0 : n;
 }
 
-}  // namespace
+}  // namespace ofarn_host
 
 extern "C" {
 #pragma GCC visibility push(default)

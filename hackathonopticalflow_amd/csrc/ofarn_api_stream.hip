@@ -71,6 +71,7 @@ int stream_turn(ofarn_ctx *c, hipStream_t s, const uint8_t *d_gray, int w, int h
     st.cur = had ? st.cur ^ 1 : 0;
     st.have = true;
     st.turns++;
+    st.view_flow_valid = had && d_flow == c->st_flow && d_flow != nullptr;
     return had ? OFARN_OK : OFARN_STREAM_PRIMED;
 }
 
@@ -215,6 +216,94 @@ int ofarn_stream_next_danger(ofarn_ctx *c, const uint8_t *h_gray, int w, int h, 
                              uint8_t *h_v)
 {
     return stream_next_host(c, h_gray, 0, w, h, stride, h_flow, h_mask, h_v);
+}
+
+// The frame loop's per-frame OUTPUTS without the flow field crossing PCIe.  What the reference does with `flow` each turn is draw it:
+// draw_flow samples it on a step-14 grid and draws arrows (DenseOF.py:40-49, :574), draw_hsv paints the rainbow (DenseOF.py:109-124,
+// :578), and the danger points come from the grid filter (pathfinder_viewer.py:159-176, 204-217).  Those results are KBs (the arrow
+// end points, mask + V) or a third of the flow's size (the rainbow, 3 B instead of 8 B per pixel); the 16.6 MB flow field itself
+// stays in HBM (st_flow) -- a synchronous 1080p turn then costs its kernels plus microseconds of transfer instead of + 0.33 ms.
+int ofarn_stream_next_view(ofarn_ctx *c, const uint8_t *h_frame, int bgr, int w, int h, int stride, uint8_t *h_mask, uint8_t *h_v,
+                           int arrow_step, int32_t *h_lines, uint8_t *h_rainbow)
+{
+    int rc = stream_check(c, w, h);
+    if (rc) return rc;
+    const int bpp = bgr ? 3 : 1;
+    if (!h_frame) return fail(OFARN_E_INVALID, "frame is NULL");
+    if (stride < w * bpp) return fail(OFARN_E_INVALID, "stride %d < row bytes %d", stride, w * bpp);
+    if ((h_mask == nullptr) != (h_v == nullptr)) return fail(OFARN_E_INVALID, "danger mask and v must be given together");
+    if (h_lines && arrow_step < 1) return fail(OFARN_E_INVALID, "arrow_step must be >= 1, got %d", arrow_step);
+    if (c->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW)
+        return fail(OFARN_E_UNSUPPORTED, "ofarn_stream_next_view keeps the flow on the device and has no initial-flow input: use ofarn_stream_next");
+    ofarn_ctx::Stream &st = c->stream_state;
+    const size_t fsz = (size_t)w * h;
+    double astart = 0;
+    const int nx = h_lines ? arrow_axis(w, arrow_step, &astart) : 0, ny = h_lines ? arrow_axis(h, arrow_step, &astart) : 0;
+    const size_t K = (size_t)nx * ny, lines_bytes = K * 4 * sizeof(int32_t), rb_bytes = h_rainbow ? fsz * 3 : 0;
+    const size_t P = (h_mask && c->P > 0) ? (size_t)c->P : 0;
+    // device view buffer: [lines | mask | v | pad to 256 | rainbow]: the small results leave in ONE transfer into a page-locked landing
+    // zone (three pageable copies of a few KB each cost ~15 us apiece in call overhead) and are copied on from there by the host
+    const size_t small = lines_bytes + 2 * P, small_pad = (small + 255) & ~(size_t)255;
+    if ((rc = grow_u8(c, &st.d_frame, &st.frame_cap, fsz, "streaming frame buffer"))) return rc;
+    if (bgr && (rc = grow_u8(c, &st.d_bgr, &st.bgr_cap, fsz * 3, "streaming BGR buffer"))) return rc;
+    if ((rc = grow_u8(c, &st.d_view, &st.view_cap, small_pad + rb_bytes + 16, "view buffer"))) return rc;
+    if ((rc = ensure_staging(c, 0, fsz * 2 * sizeof(float), 0))) return rc;
+    if (small > st.h_view_cap) {
+        if (st.h_view) { (void)hipHostFree(st.h_view); st.h_view = nullptr; st.h_view_cap = 0; }
+        if (hipHostMalloc((void **)&st.h_view, small_pad, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            st.h_view = nullptr;
+            return fail(OFARN_E_NOMEM, "page-locked view buffer of %zu bytes could not be allocated", small_pad);
+        }
+        st.h_view_cap = small_pad;
+    }
+    int32_t *d_lines = reinterpret_cast<int32_t *>(st.d_view);
+    uint8_t *d_mask = st.d_view + lines_bytes, *d_v = d_mask + P, *d_rb = st.d_view + small_pad;
+    hipStream_t s = c->stream;
+    if ((rc = begin_call(c, s))) return rc;
+    uint8_t *dst = bgr ? st.d_bgr : st.d_frame;
+    if (stride == w * bpp) HIP_TRY(hipMemcpyAsync(dst, h_frame, fsz * bpp, hipMemcpyHostToDevice, s));
+    else HIP_TRY(hipMemcpy2DAsync(dst, (size_t)w * bpp, h_frame, stride, (size_t)w * bpp, h, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(c->ev0, s));
+    if (bgr)
+        timed(c, s, OFARN_STAGE_BGR2GRAY, 0, (double)fsz, [&] { launch_bgr2gray(s, st.d_bgr, st.d_frame, fsz, kGrayB, kGrayG, kGrayR, kGrayShift); });
+    const int turn = stream_turn(c, s, st.d_frame, w, h, c->st_flow, P ? d_mask : nullptr, P ? d_v : nullptr);
+    if (turn < 0) { (void)end_call(c, s); return turn; }
+    if (turn == OFARN_OK) {
+        if (h_lines && K > 0) launch_flow_arrows(s, c->st_flow, w, h, 1, nx, ny, astart, (double)arrow_step, d_lines);
+        if (h_rainbow) launch_flow_hsv(s, c->st_flow, fsz, nullptr, d_rb);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(c->ev1, s));
+    if (turn == OFARN_OK) {
+        if (small) HIP_TRY(hipMemcpyAsync(st.h_view, st.d_view, small, hipMemcpyDeviceToHost, s));
+        if (h_rainbow) HIP_TRY(hipMemcpyAsync(h_rainbow, d_rb, rb_bytes, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    if (turn == OFARN_OK) {
+        if (h_lines && K > 0) memcpy(h_lines, st.h_view, lines_bytes);
+        if (P) { memcpy(h_mask, st.h_view + lines_bytes, P); memcpy(h_v, st.h_view + lines_bytes + P, P); }
+    }
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_ms = ms;
+    rc = end_call(c, s);
+    return rc ? rc : turn;
+}
+
+// The flow field of the most recent ofarn_stream_next_view turn, fetched after the fact (device staging -> host).
+int ofarn_stream_view_flow(ofarn_ctx *c, int w, int h, float *h_flow)
+{
+    if (!c || !h_flow) return fail(OFARN_E_INVALID, "ctx or flow is NULL");
+    const ofarn_ctx::Stream &st = c->stream_state;
+    if (!(st.have && st.view_flow_valid && st.w == w && st.h == h) || !c->st_flow)
+        return fail(OFARN_E_INVALID, "no streaming turn of %dx%d has produced a flow on this context yet", w, h);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = begin_call(c, c->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h_flow, c->st_flow, (size_t)w * h * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return end_call(c, c->stream);
 }
 
 // Pipelined submission: enqueue the turn and return; the flow lands in h_flow asynchronously (copy stream), while the caller

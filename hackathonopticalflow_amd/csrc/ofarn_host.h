@@ -119,6 +119,11 @@ struct ofarn_ctx {
         uint8_t *d_frame = nullptr;     // the new gray frame (host entry points / BGR input)
         uint8_t *d_bgr = nullptr;
         size_t frame_cap = 0, bgr_cap = 0;
+        uint8_t *d_view = nullptr;      // ofarn_stream_next_view: arrow lines + rainbow image of the turn, on the device
+        size_t view_cap = 0;
+        uint8_t *h_view = nullptr;      // page-locked landing zone of the small results (mask, v, lines): one transfer, then host copies
+        size_t h_view_cap = 0;
+        bool view_flow_valid = false;   // c->st_flow holds the flow of the most recent turn (ofarn_stream_next_view)
         unsigned long long turns = 0;
         // pipelined submission (ofarn_stream_submit / ofarn_stream_wait): two device flow buffers used in turn, a copy stream whose
         // device-to-host transfer of turn t runs beside the kernels of turn t+1
@@ -175,6 +180,8 @@ inline hipStream_t pick_stream(const ofarn_ctx *c, void *hip_stream)
     return hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
 }
 
+// ofarn_api_extras.hip: np.mgrid[step/2:size:step] of draw_flow (DenseOF.py:44): count and float start
+int arrow_axis(int size, int step, double *start);
 // ofarn_api.hip
 int check_size(ofarn_ctx *c, int w, int h);
 int make_plan(ofarn_ctx *c, int w, int h);

@@ -123,6 +123,9 @@ ABI = {
                                            C.c_void_p]),
     "ofarn_stream_next_device_bgr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p]),
+    "ofarn_stream_next_view": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_void_p]),
+    "ofarn_stream_view_flow": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ofarn_stream_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ofarn_stream_wait": (C.c_int, [C.c_void_p, C.c_int]),
     "ofarn_stream_reset": (C.c_int, [C.c_void_p]),
@@ -488,6 +491,55 @@ class FarnebackEngine:
         if rc == OFARN_STREAM_PRIMED:
             return (None, None, None) if want_danger else None
         return (out, mask, v) if want_danger else out
+
+    def stream_next_view(self, frame, danger=True, arrows=14, rainbow=False, out=None):
+        """One turn of the frame loop returning what the reference DRAWS from the flow instead of the flow itself (the 16.6 MB
+        field stays in HBM): a dict with "mask", "v" (danger map, pathfinder_viewer.py:159-176, 204-217), "lines" (draw_flow's
+        int32[K,2,2] arrow end points for step `arrows`, DenseOF.py:40-49) and "rainbow" (draw_hsv's BGR image, DenseOF.py:109-124),
+        each present if asked for; None for the first frame of a session.  `out`: a dict from an earlier call whose arrays are
+        reused (page-locked ones make the small transfers asynchronous).  stream_view_flow() fetches the flow of the turn."""
+        a = np.asarray(frame)
+        bgr = a.ndim == 3 and a.shape[2] == 3
+        if not bgr:
+            a = _as_gray(a, "frame")
+        elif a.dtype != np.uint8:
+            raise ValueError(f"frame must be uint8, got {a.dtype}")
+        h, w = a.shape[:2]
+        if a.strides[-1] != 1 or (bgr and a.strides[1] != 3) or a.strides[0] < w * (3 if bgr else 1):
+            a = np.ascontiguousarray(a)
+        res = {} if out is None else out
+        vp = lambda x: C.c_void_p(x.ctypes.data) if x is not None else None
+
+        def buf(key, shape, dtype):
+            x = res.get(key)
+            if not (isinstance(x, np.ndarray) and x.shape == shape and x.dtype == dtype and x.flags.c_contiguous):
+                x = res[key] = np.zeros(shape, dtype)
+            return x
+        mask = v = lines = rb = None
+        if danger:
+            P = len(grid_points(w, h, self.params.grid_step))
+            mask, v = buf("mask", (P,), np.uint8), buf("v", (P,), np.uint8)
+        step = 0
+        if arrows:
+            step = int(arrows)
+            K = self._lib.ofarn_flow_arrow_count(w, h, step, None, None)
+            if K < 0:
+                _raise(K)
+            lines = buf("lines", (K, 2, 2), np.int32)
+        if rainbow:
+            rb = buf("rainbow", (h, w, 3), np.uint8)
+        rc = self._lib.ofarn_stream_next_view(self._h, C.c_void_p(a.ctypes.data), int(bgr), w, h, a.strides[0], vp(mask), vp(v), step,
+                                              vp(lines), vp(rb))
+        if rc < 0:
+            _raise(rc)
+        return None if rc == OFARN_STREAM_PRIMED else res
+
+    def stream_view_flow(self, width, height, flow=None):
+        """The flow field of the most recent stream_next_view turn (it stayed on the device), as float32[H,W,2]."""
+        out = flow if (isinstance(flow, np.ndarray) and flow.dtype == np.float32 and flow.shape == (height, width, 2)
+                       and flow.flags.c_contiguous) else np.empty((height, width, 2), np.float32)
+        _check(self._lib.ofarn_stream_view_flow(self._h, width, height, C.c_void_p(out.ctypes.data)))
+        return out
 
     def stream_next_device(self, d_frame, width, height, d_flow=None, d_mask=None, d_v=None, stream=None, bgr=False) -> bool:
         """Device-resident turn (torch CUDA tensors or raw addresses), enqueued on `stream`, not synchronised.  Returns True when
@@ -956,6 +1008,28 @@ class FlowStream:
         return (flow, out[1], out[2]) if want_danger else flow
 
     __call__ = next
+
+    def next_view(self, frame, danger=True, arrows=14, rainbow=False):
+        """Synchronous turn that returns what the viewer draws -- {"mask", "v", "lines", "rainbow"} as asked for -- and leaves the flow
+        field on the device (view_flow() fetches it): FarnebackEngine.stream_next_view.  None for the first frame.  The returned
+        dict and its arrays are reused by the next call."""
+        a = np.asarray(frame)
+        if a.ndim not in (2, 3):
+            raise ValueError(f"frame must be uint8[H,W] or uint8[H,W,3], got shape {a.shape}")
+        h, w = a.shape[:2]
+        eng = self._engine(h, w)
+        if self._pending:
+            eng.stream_wait(0)
+            self._pending = []
+        if getattr(self, "_view", None) is None or self._view_shape != (h, w):
+            self._view, self._view_shape = {}, (h, w)
+        if rainbow and "rainbow" not in self._view:
+            self._view["rainbow"] = pinned_empty((h, w, 3), np.uint8)     # 6.2 MB at 1080p: page-locked, so it crosses PCIe at link rate
+        return eng.stream_next_view(a, danger=danger, arrows=arrows, rainbow=rainbow, out=self._view)
+
+    def view_flow(self):
+        h, w = self._shape
+        return self._eng.stream_view_flow(w, h)
 
     def flush(self):
         """Pipelined mode: waits for the turn in flight and returns its flow (None if there is none)."""

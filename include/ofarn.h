@@ -132,6 +132,15 @@ int ofarn_stream_next_device(ofarn_ctx *ctx, const uint8_t *d_gray, int w, int h
                              uint8_t *d_v, void *hip_stream);
 int ofarn_stream_next_device_bgr(ofarn_ctx *ctx, const uint8_t *d_bgr, int w, int h, float *d_flow, uint8_t *d_mask,
                                  uint8_t *d_v, void *hip_stream);
+/* The loop's per-frame OUTPUTS without the flow field crossing PCIe.  What the reference does with `flow` each turn is draw it:
+ * draw_flow's arrows on a step-14 grid (DenseOF.py:40-49, :574), draw_hsv's rainbow (DenseOF.py:109-124, :578), the danger points of
+ * the grid filter (pathfinder_viewer.py:159-176, 204-217).  This turn returns exactly those -- h_mask / h_v uint8[P] (together or both
+ * NULL), h_lines int32[K][2][2] with K = ofarn_flow_arrow_count(w, h, arrow_step) (or NULL), h_rainbow uint8[h][w][3] BGR (or NULL)
+ * -- and keeps the float32[h][w][2] flow in HBM; ofarn_stream_view_flow fetches it afterwards if it is wanted after all.
+ * h_frame: gray (bgr = 0) or packed BGR (bgr != 0), `stride` bytes per row.  Returns as ofarn_stream_next. */
+int ofarn_stream_next_view(ofarn_ctx *ctx, const uint8_t *h_frame, int bgr, int w, int h, int stride, uint8_t *h_mask,
+                           uint8_t *h_v, int arrow_step, int32_t *h_lines, uint8_t *h_rainbow);
+int ofarn_stream_view_flow(ofarn_ctx *ctx, int w, int h, float *h_flow);
 /* Pipelined form for throughput: ofarn_stream_submit enqueues the turn (upload, kernels, transfer of the flow into h_flow on a copy
  * stream) and returns without waiting; the caller submits the next frame at once, whose kernels then run BESIDE this turn's
  * device-to-host transfer (at 1080p the 16.6 MB of flow take about as long over PCIe as the kernels).  h_flow of a turn is complete

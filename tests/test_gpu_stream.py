@@ -358,3 +358,35 @@ def test_stream_4k_levels6_iterations5(H):
         assert got[0] is None and got[1] is None
         np.testing.assert_array_equal(got[2], want[0])
         np.testing.assert_array_equal(got[3], want[1])
+
+
+def test_view_turn_returns_what_the_viewer_draws(H, oracle):
+    """ofarn_stream_next_view: the per-frame outputs of the reference's loop -- danger map, draw_flow's arrow lines, draw_hsv's
+    rainbow -- computed from the turn's flow ON the device; the flow itself does not cross PCIe but can be fetched afterwards.  Every
+    output equals what the separate entry points give on the pair call's flow."""
+    w, h = 320, 240
+    fr = video(5, h, w, 51)
+    bgr = np.stack([np.stack([g, g, g], -1) for g in fr])
+    with H.FlowStream(levels=3) as st, H.FarnebackEngine(w, h, 1, levels=3) as eng:
+        assert st.next_view(fr[0]) is None
+        for i in range(1, 5):
+            frame = bgr[i] if i % 2 == 0 else fr[i]            # gray and BGR frames alternate (gray as BGR converts back to itself)
+            res = st.next_view(frame, danger=True, arrows=14, rainbow=True)
+            flow = eng.calc(fr[i - 1], fr[i])
+            np.testing.assert_array_equal(st.view_flow(), flow)
+            np.testing.assert_array_equal(flow, oracle.farneback(fr[i - 1], fr[i], levels=3, box_mode=oracle.BOX_BLOCKED))
+            mask, v = eng.danger_map(flow)
+            np.testing.assert_array_equal(res["mask"], mask)
+            np.testing.assert_array_equal(res["v"], v)
+            np.testing.assert_array_equal(res["lines"], eng.flow_arrows(flow, 14))
+            np.testing.assert_array_equal(res["rainbow"], eng.flow_hsv(flow))
+        # only the danger map; then an ordinary turn continues the session, after which the device no longer holds a view flow
+        res = st.next_view(fr[0], arrows=None)
+        assert set(res) >= {"mask", "v"}
+        np.testing.assert_array_equal(res["mask"], eng.danger_map(eng.calc(fr[4], fr[0]))[0])
+        np.testing.assert_array_equal(st.next(fr[1]), eng.calc(fr[0], fr[1]))
+        with pytest.raises(ValueError):
+            st.view_flow()
+    with H.FarnebackEngine(w, h, 1, levels=3, flags=4) as eng:
+        with pytest.raises(NotImplementedError):
+            eng.stream_next_view(fr[0])
