@@ -753,6 +753,10 @@ def test_headless_viewer_example(H):
     np.testing.assert_array_equal(masks, out["dense_mask"])
     np.testing.assert_array_equal(vs, out["dense_v"])
     assert np.abs(flows.mean(axis=(1, 2)) - out["mean_flow"]).max() < 1e-4
+    vm, vv, vl = mod.run_loop_view(frames)
+    np.testing.assert_array_equal(vm, out["dense_mask"])
+    np.testing.assert_array_equal(vv, out["dense_v"])
+    np.testing.assert_array_equal(vl, out["lines"])
 
 
 def test_lk_batch_points_per_pair_and_forward_direction(H, oracle):
