@@ -12,6 +12,7 @@
 //            T = v[0] + ... + v[B-1] (left to right), S(j) = S(j-1) - v[j-1], P'(j) = v[B] + ... + v[B+j-1], colsum(j) = S(j) + P'(j)
 //   rows:    the 2m+1 column sums in chunks of three, left to right
 // so the results are bit-identical to the other two paths (tests/test_gpu_parity.py runs the pipeline tests on both).
+#include "farneback_device.h"
 #include "flow_iter_common.h"
 #include "ofarn_internal.h"
 
@@ -19,7 +20,15 @@
 
 namespace ofarn {
 
-constexpr int TI_TW = 32;   // output columns per tile
+// Output columns per tile.  30, not 32: with m = 7 the two LDS arrays are then 51.9 KB instead of 54.3 KB, so THREE blocks fit a CU's 160 KB
+// instead of two (a 960 x 540 level of one pair: 68 instead of 79 us for its three iterations; 24 columns: 70 us).
+#ifndef OFARN_TILE_TW
+#define OFARN_TILE_TW 30
+#endif
+constexpr int TI_TW = OFARN_TILE_TW;
+#ifndef OFARN_TILE_PB
+#define OFARN_TILE_PB 3     // pixels whose loads a thread of phase 1 keeps in flight together (measured: 3 and 6 alike, 1 slower)
+#endif
 
 template <int M_, int MODE>   // MODE 0: flow_in == 0;  1: flow_in = upsample(coarse)*mul;  2: flow_in from HBM
 __global__ __launch_bounds__(256) void k_flow_iter_tile(const float *__restrict__ R, int fstep, const float2 *__restrict__ flow_in,
@@ -38,34 +47,67 @@ __global__ __launch_bounds__(256) void k_flow_iter_tile(const float *__restrict_
     const float2 *fin = MODE == 2 ? flow_in + p * npx : nullptr;
     const float2 *coarse = MODE == 1 ? up.coarse + p * (size_t)up.cw * up.ch : nullptr;
 
-    // ---- phase 1: FarnebackUpdateMatrices of every pixel the tile's windows touch, one thread per pixel
-    for (int i = tid; i < NT * IW; i += 256) {
-        const int t = i / IW, ix = i - t * IW;
-        const int x = clampi(x0 - M_ + ix, 0, w - 1), y = clampi(yb + t - M_, 0, h - 1);
-        float dx = 0.f, dy = 0.f;
+    // ---- phase 1: FarnebackUpdateMatrices of every pixel the tile's windows touch, one thread per pixel, PB pixels per thread at a
+    // time: their flow loads are issued together, then their gathers (R0 + the four taps of R1), then the arithmetic -- two memory round
+    // trips per batch instead of two per pixel (a tile has 5.2 pixels per thread; the launch is latency bound).  gather_issue +
+    // matrices_finish are the marching kernel's split of update_matrices_px: the same operations in the same order.
+    constexpr int PB = OFARN_TILE_PB;
+    for (int base = tid; base < NT * IW; base += 256 * PB) {
+        int px[PB], py[PB], pt[PB], pix[PB];
+        bool live[PB];
+#pragma unroll
+        for (int q = 0; q < PB; q++) {
+            const int i = base + q * 256;
+            live[q] = i < NT * IW;
+            const int ii = live[q] ? i : 0;
+            pt[q] = ii / IW; pix[q] = ii - pt[q] * IW;
+            px[q] = clampi(x0 - M_ + pix[q], 0, w - 1); py[q] = clampi(yb + pt[q] - M_, 0, h - 1);
+        }
+        float dx[PB], dy[PB];
         if (MODE == 2) {
-            const float2 f = fin[(size_t)y * w + x];
-            dx = f.x; dy = f.y;
+            float2 f[PB];
+#pragma unroll
+            for (int q = 0; q < PB; q++) f[q] = fin[(size_t)py[q] * w + px[q]];
+#pragma unroll
+            for (int q = 0; q < PB; q++) { dx[q] = f[q].x; dy[q] = f[q].y; }
         } else if (MODE == 1) {
             // resize(INTER_LINEAR) of the coarse flow, then * 1/pyr_scale: the operations of k_flow_upsample / k_flow_iter's MODE 1
-            const int sx = up.xofs[x], sx1 = sx + 1 < up.cw ? sx + 1 : up.cw - 1;
-            const float a1 = up.xa[x], a0 = 1.f - a1;
-            int sy;
-            float b1;
-            resize_coord(y, up.yscale, up.ch, sy, b1);
-            const int sy1 = sy + 1 < up.ch ? sy + 1 : up.ch - 1;
-            const float b0 = 1.f - b1;
-            const float2 p00 = coarse[(size_t)sy * up.cw + sx], p01 = coarse[(size_t)sy * up.cw + sx1];
-            const float2 p10 = coarse[(size_t)sy1 * up.cw + sx], p11 = coarse[(size_t)sy1 * up.cw + sx1];
-            const float r0x = p00.x * a0 + p01.x * a1, r0y = p00.y * a0 + p01.y * a1;
-            const float r1x = p10.x * a0 + p11.x * a1, r1y = p10.y * a0 + p11.y * a1;
-            dx = (r0x * b0 + r1x * b1) * up.mul;
-            dy = (r0y * b0 + r1y * b1) * up.mul;
-        }
-        float m[5];
-        update_matrices_px(R0, R1, npx, w, h, x, y, dx, dy, m);
+            float2 p00[PB], p01[PB], p10[PB], p11[PB];
+            float a1[PB], b1[PB];
 #pragma unroll
-        for (int c = 0; c < 5; c++) sM[c][t][ix] = m[c];
+            for (int q = 0; q < PB; q++) {
+                const int sx = up.xofs[px[q]], sx1 = sx + 1 < up.cw ? sx + 1 : up.cw - 1;
+                a1[q] = up.xa[px[q]];
+                int sy;
+                resize_coord(py[q], up.yscale, up.ch, sy, b1[q]);
+                const int sy1 = sy + 1 < up.ch ? sy + 1 : up.ch - 1;
+                p00[q] = coarse[(size_t)sy * up.cw + sx]; p01[q] = coarse[(size_t)sy * up.cw + sx1];
+                p10[q] = coarse[(size_t)sy1 * up.cw + sx]; p11[q] = coarse[(size_t)sy1 * up.cw + sx1];
+            }
+#pragma unroll
+            for (int q = 0; q < PB; q++) {
+                const float a0 = 1.f - a1[q], b0 = 1.f - b1[q];
+                const float r0x = p00[q].x * a0 + p01[q].x * a1[q], r0y = p00[q].y * a0 + p01[q].y * a1[q];
+                const float r1x = p10[q].x * a0 + p11[q].x * a1[q], r1y = p10[q].y * a0 + p11[q].y * a1[q];
+                dx[q] = (r0x * b0 + r1x * b1[q]) * up.mul;
+                dy[q] = (r0y * b0 + r1y * b1[q]) * up.mul;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PB; q++) { dx[q] = 0.f; dy[q] = 0.f; }
+        }
+        GatherRaw g[PB];
+#pragma unroll
+        for (int q = 0; q < PB; q++) gather_issue(R0, R1, npx, w, h, px[q], py[q], dx[q], dy[q], g[q]);
+#pragma unroll
+        for (int q = 0; q < PB; q++) {
+            float m[5];
+            matrices_finish(g[q], border_x(px[q], w), border_applies(px[q], w), h, py[q], m);
+            if (live[q]) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) sM[c][pt[q]][pix[q]] = m[c];
+            }
+        }
     }
     __syncthreads();
 
