@@ -786,13 +786,16 @@ __device__ __forceinline__ int reflect101_once(int p, int len)   // valid for -l
 //               unpacked with v_cvt_f32_ubyteN.
 // EDGE = true : level columns 0 and w-1 (the only ones whose taps cross the left / right border for these
 //               (S, K)), byte loads at reflect-101 indices; thread = (strip, column), a tiny second launch.
-template <int S, int K, bool EDGE>
+// SYMM (K == 3 only): the row pass in SymmRowSmallFilter's order (row_small_symm) -- a template parameter, not a run-time flag: a
+// run-time branch inside the row pass kept the compiler from batching the rows' loads (1.15 -> 1.63 ms per 1024 frames at level 1).
+template <int S, int K, bool EDGE, bool SYMM>
 __global__ __launch_bounds__(EDGE ? 64 : 256) void k_level_direct(const uint8_t *__restrict__ frames, size_t frame_stride,
                                                                   int W, int H, TapsArg<K> taps, float *__restrict__ I, int w,
-                                                                  int h, int strip, int symm)
+                                                                  int h, int strip)
 {
     constexpr int R = 3 * S, r = K / 2;
     static_assert(K + 1 <= R && (K & 1), "ring of 3*S rows must hold the K+1 rows of one output");
+    static_assert(!SYMM || K == 3, "the small-symmetric order exists for 3 taps here");
     int x, dy0;
     if (EDGE) {
         const int sidx = blockIdx.y * 32 + (threadIdx.x >> 1);
@@ -810,27 +813,26 @@ __global__ __launch_bounds__(EDGE ? 64 : 256) void k_level_direct(const uint8_t 
     const int cl = S * x + S / 2 - 1 - r;            // source column of tap 0 of the left sampled column
     float ring[R][2];
 
-    // row pass of virtual source row v (reflected into the frame) at the two sampled columns
-    auto rowpass = [&](int v, float &o0, float &o1) {
+    // The K+1 source bytes of a row pass arrive as ND dwords: aligned ones for S >= 4 (the window start has the same alignment for
+    // every x), one unaligned dword for S = 2 (K + 1 = 4 bytes from cl; global loads need no alignment); EDGE: bytes at reflected indices.
+    constexpr int OFF = S >= 4 ? (((S / 2 - 1 - r) % 4) + 4) % 4 : 0;     // cl - (cl rounded down to a multiple of 4)
+    constexpr int ND = EDGE ? K + 1 : (OFF + K + 1 + 3) / 4;
+    auto rowload = [&](int v, uint32_t (&d)[ND]) {
         const uint8_t *row = f + (size_t)reflect101_once(v, H) * W;
-        float px[K + 1];
         if (EDGE) {
 #pragma unroll
-            for (int t = 0; t <= K; t++) px[t] = (float)row[reflect101_once(cl + t, W)];
-        } else if (S >= 4) {
-            constexpr int OFF = (((S / 2 - 1 - r) % 4) + 4) % 4;     // cl - (cl rounded down to a multiple of 4)
-            constexpr int ND = (OFF + K + 1 + 3) / 4;
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(row + (cl - OFF));
-            uint32_t d[ND];
-#pragma unroll
-            for (int i = 0; i < ND; i++) d[i] = q[i];
-#pragma unroll
-            for (int t = 0; t <= K; t++) px[t] = (float)((d[(OFF + t) / 4] >> (8 * ((OFF + t) % 4))) & 255u);
+            for (int t = 0; t <= K; t++) d[t] = row[reflect101_once(cl + t, W)];
         } else {
 #pragma unroll
-            for (int t = 0; t <= K; t++) px[t] = (float)row[cl + t];
+            for (int i = 0; i < ND; i++) __builtin_memcpy(&d[i], row + (cl - OFF) + 4 * i, 4);
         }
-        if (K == 3 && symm) {                          // SymmRowSmallFilter's order (row_small_symm)
+    };
+    auto rowcalc = [&](const uint32_t (&d)[ND], float &o0, float &o1) {
+        float px[K + 1];
+#pragma unroll
+        for (int t = 0; t <= K; t++)
+            px[t] = EDGE ? (float)d[t] : (float)((d[(OFF + t) / 4] >> (8 * ((OFF + t) % 4))) & 255u);
+        if (SYMM) {                                    // SymmRowSmallFilter's order (row_small_symm)
             o0 = px[1] * taps.k[1] + (px[0] + px[2]) * taps.k[2];
             o1 = px[2] * taps.k[1] + (px[1] + px[3]) * taps.k[2];
             return;
@@ -846,18 +848,48 @@ __global__ __launch_bounds__(EDGE ? 64 : 256) void k_level_direct(const uint8_t 
     };
     const int vbase = S * dy0 + S / 2 - 1 - r;       // virtual source row of ring slot 0
     // warm-up: the K+1-S rows the first output needs beyond its own S new ones
+    {
+        constexpr int NW = K + 1 - S;
+        uint32_t wd[NW > 0 ? NW : 1][ND];
 #pragma unroll
-    for (int j = 0; j < K + 1 - S; j++) rowpass(vbase + j, ring[j % R][0], ring[j % R][1]);
-
+        for (int j = 0; j < NW; j++) rowload(vbase + j, wd[j]);
+#pragma unroll
+        for (int j = 0; j < NW; j++) rowcalc(wd[j], ring[j % R][0], ring[j % R][1]);
+    }
+    // The S new source rows of an output row are LOADED one output row ahead: their latency then overlaps the previous row's
+    // row passes, column pass and store instead of standing in front of every row pass (the kernel is bound by exactly that
+    // latency: its waves wait 84 % of their cycles).
+    // (S = 2 only: at S = 4 and 8 the 2 x S x ND registers of such a prefetch cost more occupancy than the overlap returns --
+    // 0.39 / 0.46 instead of 0.37 / 0.38 ms per 512 frames -- and the compiler batches the S row loads of an output row by itself.)
+    constexpr bool PREFETCH = S == 2 && !EDGE;
+    uint32_t nxt[PREFETCH ? S : 1][ND];
+    if (PREFETCH && dy0 < dy1) {
+#pragma unroll
+        for (int jj = 0; jj < S; jj++) rowload(vbase + K + 1 - S + jj, nxt[PREFETCH ? jj : 0]);
+    }
     for (int dy = dy0; dy < dy1; dy += 3) {
         const int vg = vbase + S * (dy - dy0);       // virtual row of slot 0 for this group of three outputs
 #pragma unroll
         for (int b = 0; b < 3; b++) {
             if (dy + b < dy1) {
+                uint32_t cur[S][ND];
+                if (PREFETCH) {
+#pragma unroll
+                    for (int jj = 0; jj < S; jj++)
+#pragma unroll
+                        for (int i = 0; i < ND; i++) cur[jj][i] = nxt[PREFETCH ? jj : 0][i];
+                    if (dy + b + 1 < dy1) {
+#pragma unroll
+                        for (int jj = 0; jj < S; jj++) rowload(vg + S * (b + 1) + K + 1 - S + jj, nxt[PREFETCH ? jj : 0]);
+                    }
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < S; jj++) rowload(vg + S * b + K + 1 - S + jj, cur[jj]);
+                }
 #pragma unroll
                 for (int jj = 0; jj < S; jj++) {
                     const int j = K + 1 - S + jj;
-                    rowpass(vg + S * b + j, ring[(S * b + j) % R][0], ring[(S * b + j) % R][1]);
+                    rowcalc(cur[jj], ring[(S * b + j) % R][0], ring[(S * b + j) % R][1]);
                 }
                 float bb[2][2];
 #pragma unroll
@@ -1007,9 +1039,9 @@ bool level_direct_supported(const void *frames, int W, int H, int w, int h, int 
            (W == 8 * w && H == 8 * h && ksize == 19);
 }
 
-template <int S, int K>
+template <int S, int K, bool SYMM>
 static void launch_level_direct_sk(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
-                                   const float *h_kern, float *I, int w, int h, int symm)
+                                   const float *h_kern, float *I, int w, int h)
 {
     TapsArg<K> taps;
     for (int i = 0; i < K; i++) taps.k[i] = h_kern[i];
@@ -1020,21 +1052,23 @@ static void launch_level_direct_sk(hipStream_t s, const uint8_t *frames, size_t 
         const int nt = w - 2 > 128 ? 256 : (w - 2 > 64 ? 128 : 64);
         const int strip = 3 * best_strip_units(units, 3 * S, K + 1 - S, (int)cdivu(w - 2, nt) * nframes, 8 * (256 / nt));
         dim3 grid(cdivu(w - 2, nt), cdivu(h, strip), nframes);
-        hipLaunchKernelGGL((k_level_direct<S, K, false>), grid, dim3(nt), 0, s, frames, frame_stride, W, H, taps, I, w, h, strip, symm);
+        hipLaunchKernelGGL((k_level_direct<S, K, false, SYMM>), grid, dim3(nt), 0, s, frames, frame_stride, W, H, taps, I, w, h, strip);
     }
     // border columns 0 and w-1: 32 strips of at least 12 rows per block of 64 threads
     int estrip = 3 * ((units + 31) / 32);
     if (estrip < 12) estrip = 12;
     dim3 egrid(1, cdivu((int)cdivu(h, estrip), 32), nframes);
-    hipLaunchKernelGGL((k_level_direct<S, K, true>), egrid, dim3(64), 0, s, frames, frame_stride, W, H, taps, I, w, h, estrip, symm);
+    hipLaunchKernelGGL((k_level_direct<S, K, true, SYMM>), egrid, dim3(64), 0, s, frames, frame_stride, W, H, taps, I, w, h, estrip);
 }
 
 void launch_level_direct(hipStream_t s, const uint8_t *frames, size_t frame_stride, int W, int H, int nframes,
                          const float *h_kern, int ksize, float *I, int w, int h, int symm)
 {
-    if (W == 2 * w && ksize == 3) launch_level_direct_sk<2, 3>(s, frames, frame_stride, W, H, nframes, h_kern, I, w, h, symm);
-    else if (W == 4 * w && ksize == 9) launch_level_direct_sk<4, 9>(s, frames, frame_stride, W, H, nframes, h_kern, I, w, h, 0);
-    else if (W == 8 * w && ksize == 19) launch_level_direct_sk<8, 19>(s, frames, frame_stride, W, H, nframes, h_kern, I, w, h, 0);
+    if (W == 2 * w && ksize == 3) {
+        if (symm) launch_level_direct_sk<2, 3, true>(s, frames, frame_stride, W, H, nframes, h_kern, I, w, h);
+        else launch_level_direct_sk<2, 3, false>(s, frames, frame_stride, W, H, nframes, h_kern, I, w, h);
+    } else if (W == 4 * w && ksize == 9) launch_level_direct_sk<4, 9, false>(s, frames, frame_stride, W, H, nframes, h_kern, I, w, h);
+    else if (W == 8 * w && ksize == 19) launch_level_direct_sk<8, 19, false>(s, frames, frame_stride, W, H, nframes, h_kern, I, w, h);
 }
 
 // The fused kernel is instantiated for the window half-widths m = winsize/2 = 3..10 (winsize 6..21); other window
