@@ -508,17 +508,23 @@ __global__ __launch_bounds__(FI_THREADS) void k_polyexp_march(const void *__rest
     //   SRC 0: the float level image.  SRC 1: level 0, 3-tap blur state (row pass of rows yy-1, yy, yy+1) from the bytes.
     const int xl = reflect101(xc - 1, w), xr = reflect101(xc + 1, w);
     float rpm = 0.f, rpc = 0.f, rpp = 0.f, icur = 0.f, pf = 0.f;
-    // SRC 1, marching: ONE byte per lane and row.  A lane's left / right neighbours are the bytes its neighbouring lanes have
-    // just loaded (whole-wave DPP shifts), except where a neighbouring lane does not hold the neighbouring pixel: lanes 0 and 63
-    // of a wave (the neighbour is in another wave or block) and the lanes at or beyond the frame's left / right edge (clamped
-    // columns, reflect-101 neighbours -- there xl == xr).  Those few lanes fetch ONE extra byte, f[xe], in a second, almost empty
-    // load (round 2 loaded f[xl], f[xc], f[xr] in every lane: three full byte-load instructions per row for one byte of input;
-    // the texture addresser takes as long for 64 bytes as for 64 float4).
+    // SRC 1, marching.  Default: three byte loads per lane and row (f[xl], f[xc], f[xr]).  -DOFARN_PE_ONE_LOAD builds the form VERDICT r2
+    // asked for: ONE byte per lane and row, the neighbours taken from the neighbouring lanes with whole-wave DPP shifts, except where a
+    // neighbouring lane does not hold the neighbouring pixel -- lanes 0 and 63 of a wave and the lanes at or beyond the frame's left /
+    // right edge (clamped columns, reflect-101 neighbours: there xl == xr) fetch one extra byte, f[xe], in a second, almost empty load.
+    // Bit-identical, SQ_INSTS_VMEM_RD 3.28 -> 2.20 per pixel -- and 1.5 % SLOWER in a same-box A/B (5.98 / 6.00 / 6.01 against
+    // 5.82 / 5.96 / 5.95 ms per 512 frames, alternating runs): the texture addresser's time for the byte loads was never the limit, and
+    // the divergent second load + two DPP moves + two selects per row cost a little.  Kept as a build option for the record.
+#ifdef OFARN_PE_ONE_LOAD
     const int lane = tid & 63;
     const bool edge_col = x <= 0 || x >= w - 1;              // xl == xr here
     const bool need_e = edge_col || lane == 0 || lane == 63;
     const int xe = (lane == 63 && !edge_col) ? xr : xl;
+#endif
     unsigned nc = 0, ne = 0;
+#ifndef OFARN_PE_ONE_LOAD
+    unsigned ne2 = 0;
+#endif
     int ry = -0x40000000;
     auto rowpass3 = [&](uint8_t a, uint8_t b, uint8_t cc) {
         float s = k0 * (float)a;
@@ -536,15 +542,24 @@ __global__ __launch_bounds__(FI_THREADS) void k_polyexp_march(const void *__rest
         else if (yy == ry + 1) {                         // uniform; the other cases need no new row or take the slow path
             const uint8_t *f = frm + (size_t)reflect101(yy + 1, h) * w;
             nc = f[xc];
+#ifndef OFARN_PE_ONE_LOAD        // default: three byte loads per lane and row (see below)
+            ne = f[xl];
+            ne2 = f[xr];
+#else
             if (need_e) ne = f[xe];
+#endif
         }
     };
     auto finish = [&](int yy) -> float {
         if (SRC == 0) return pf;
         if (yy == ry) return icur;
         if (yy == ry + 1) {
+#ifndef OFARN_PE_ONE_LOAD
+            const uint8_t nl = (uint8_t)ne, nr = (uint8_t)ne2;
+#else
             const unsigned dl = wave_shr1_u32(ne, nc), dr = wave_shl1_u32(ne, nc);   // lane 0 / 63 keep their own extra byte
             const uint8_t nl = (uint8_t)(edge_col ? ne : dl), nr = (uint8_t)(edge_col ? ne : dr);
+#endif
             rpm = rpc; rpc = rpp; rpp = rowpass3(nl, (uint8_t)nc, nr);
         }
         else { rpm = rowpass(reflect101(yy - 1, h)); rpc = rowpass(yy); rpp = rowpass(reflect101(yy + 1, h)); }
