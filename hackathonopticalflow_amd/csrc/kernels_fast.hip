@@ -1104,7 +1104,11 @@ static void launch_flow_iter_m(hipStream_t s, const float *R, int fstep, const f
     // strips start on block boundaries of the blocked column sums (multiples of B rows); their
     // number is chosen to minimise (rounds of resident blocks) x (rows marched per block)
     const int nblk = (h + B - 1) / B;
-    const int strip_h = B * best_strip_units(nblk, B, B - 1, (int)cdivu(w, OUTW) * npairs, 3);
+    int strip_units = best_strip_units(nblk, B, B - 1, (int)cdivu(w, OUTW) * npairs, 3);
+#ifdef OFARN_EXP_STRIP_ENV      // experiment: strip height of the level-0 launch from the environment (units of B rows)
+    if (const char *e = getenv("OFARN_FI_STRIP_UNITS")) if (w >= 1920 && atoi(e) > 0) strip_units = atoi(e);
+#endif
+    const int strip_h = B * strip_units;
     dim3 grid(cdivu(w, OUTW), cdivu(h, strip_h), npairs);
     // a grid that leaves most CUs without a block is latency bound: the tile kernel (kernels_tile.hip) does the same arithmetic
     // with all of a tile's gathers in flight at once

@@ -334,6 +334,13 @@ struct WavePlan {
     bool multi = false;
 };
 
+// The marching stage-A kernels (k_level_direct, k_level_hdirect) give each thread a long strip; they win once a wave holds
+// enough pixels to fill the chip that way: direct_min_frames counts frames of 1920 x 1080 (16: 4K from 4 frames on).
+static inline bool direct_wave(const ofarn_ctx *c, int nframes, int w, int h)
+{
+    return (double)nframes * w * h >= (double)c->direct_min_frames * (1920.0 * 1080.0);
+}
+
 void plan_wave(const ofarn_ctx *c, const uint8_t *d_frames, int nframes, int w, int h, WavePlan &p)
 {
     const int nlev = (int)c->lv.size() - 1;
@@ -345,12 +352,12 @@ void plan_wave(const ofarn_ctx *c, const uint8_t *d_frames, int nframes, int w, 
         const Level &L = c->lv[k];
         if (march0 && L.w == w && L.h == h && L.ksize == 3) continue;   // fused into the poly expansion, no level image
         p.I_need = std::max(p.I_need, (size_t)nframes * L.w * L.h);
-        if (!c->force_generic && nframes >= c->direct_min_frames && level_direct_supported(d_frames, w, h, L.w, L.h, L.ksize))
+        if (!c->force_generic && direct_wave(c, nframes, w, h) && level_direct_supported(d_frames, w, h, L.w, L.h, L.ksize))
             continue;   // built by k_level_direct, no tmp
         const size_t need = (size_t)nframes * h * L.w * 2;
         single = std::max(single, need);
         if (!ok) continue;
-        if (nframes >= c->direct_min_frames && level_hdirect_supported(d_frames, w, L.w, L.ksize))
+        if (direct_wave(c, nframes, w, h) && level_hdirect_supported(d_frames, w, L.w, L.ksize))
             p.hdirect[k] = true;   // 1/16, 1/32, 1/64 widths: row pass straight from the frames, no LDS staging
         else if (p.HL.n >= 12) { ok = false; continue; }
         else {
@@ -465,7 +472,7 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
             timed(c, sab, OFARN_STAGE_POLYEXP, k, ufr, [&] {
                 launch_polyexp_march(sab, d_frames, fsz, 1, R_ab(k), L.w, L.h, nframes, c->poly, L.h_kern3);
             });
-        } else if (!c->force_generic && nframes >= c->direct_min_frames &&
+        } else if (!c->force_generic && direct_wave(c, nframes, w, h) &&
                    level_direct_supported(d_frames, w, h, L.w, L.h, L.ksize)) {
             // exact 1/2, 1/4, 1/8 levels: row pass + column pass + resize in one kernel straight from the frames
             timed(c, sab, OFARN_STAGE_LEVEL_V, k, ufr, [&] {

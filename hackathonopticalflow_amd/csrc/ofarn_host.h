@@ -162,8 +162,9 @@ struct ofarn_ctx {
                                   // the tile kernel (OFARN_TILE when the context is created, ofarn_set_option "tile")
     int row_small_symm = 1;       // GaussianBlur row pass of a 3- or 5-tap kernel in SymmRowSmallFilter's order (oracle
                                   // OFO_ROW_SMALL_SYMM); OFARN_ROW_LTR=1 when the context is created: left to right (rounds 1-2)
-    int direct_min_frames = 32;   // k_level_direct marches long strips per thread: below this many frames in a wave the
-                                  // row-pass + column-pass pair has more parallelism and lower latency (OFARN_DIRECT_MIN_FRAMES)
+    int direct_min_frames = 16;   // k_level_direct marches long strips per thread: below this many frames of 1920 x 1080 (by pixel
+                                  // count: 4 frames of 3840 x 2160) in a wave the row-pass + column-pass pair has more parallelism
+                                  // and lower latency (OFARN_DIRECT_MIN_FRAMES)
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> prof_free;
     struct ProfAcc { int launches = 0; double ms = 0, units = 0; };

@@ -21,7 +21,7 @@ for i in range(N):
     kw = dict(levels=int(rng.integers(0, 6)), winsize=int(rng.integers(3, 27)), iterations=int(rng.integers(1, 4)),
               poly_n=int(rng.choice([3, 5, 5, 5, 7, 7])), poly_sigma=float(rng.choice([1.1, 1.2, 1.5])),
               pyr_scale=float(rng.choice([0.5, 0.5, 0.5, 0.6, 0.75, 0.8])), flags=int(rng.choice([0, 0, 0, 4, 256, 260])))
-    os.environ["OFARN_DIRECT_MIN_FRAMES"] = str(int(rng.choice([1, 32])))
+    os.environ["OFARN_DIRECT_MIN_FRAMES"] = str(int(rng.choice([0, 1000000])))
     if i % 3 == 0:      # a third of the cases on the FPV-like warped family (non-uniform sub-pixel flow + occluder)
         a, b, gt, _ = warped_pair(h, w, 50000 + i, zoom=float(rng.uniform(0.96, 1.08)), angle_deg=float(rng.uniform(-4, 4)),
                                   shift=(float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4))))

@@ -254,7 +254,7 @@ def test_row_order_of_small_gaussian_kernels(H, oracle, monkeypatch):
     left-to-right order of rounds 1-2 is still selectable on both sides (OFARN_ROW_LTR=1 when the context is created /
     oracle.set_row_small_symm(False)) and reproduces the goldens' flow_direct_row_ltr."""
     img, _, _ = translated_pair(240, 320, 9)
-    for env in ({}, {"OFARN_FORCE_GENERIC": "1"}, {"OFARN_DIRECT_MIN_FRAMES": "1"}):
+    for env in ({}, {"OFARN_FORCE_GENERIC": "1"}, {"OFARN_DIRECT_MIN_FRAMES": "0"}):
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
         for ps, lv in ((0.5, 2), (0.6, 3)):
@@ -456,16 +456,16 @@ def test_argument_errors(H):
 
 
 def test_direct_level_kernels_in_the_pipeline(H, oracle, monkeypatch):
-    """k_level_direct (stage A of the 1/2, 1/4, 1/8 levels in one kernel) is chosen for waves of >= 32 frames; force it for
-    a single pair and for a small batch and compare the whole pipeline with the oracle bit for bit."""
-    monkeypatch.setenv("OFARN_DIRECT_MIN_FRAMES", "1")
+    """k_level_direct (stage A of the 1/2, 1/4, 1/8 levels in one kernel) is chosen for waves of >= 16 frames of 1920 x 1080 (by pixel count); force it
+    for single pairs, then switch it off for a small batch, and compare the whole pipeline with the oracle bit for bit."""
+    monkeypatch.setenv("OFARN_DIRECT_MIN_FRAMES", "0")
     for (w, h, levels) in ((640, 480, 3), (328, 248, 3), (1920, 1080, 5)):
         a, b, _ = translated_pair(h, w, 41, max_shift=4)
         with H.FarnebackEngine(w, h, 1, levels=levels) as eng:
             np.testing.assert_array_equal(eng.calc(a, b), oracle.farneback(a, b, levels=levels, box_mode=oracle.BOX_BLOCKED))
     frames, _ = translated_pairs(20, 120, 160, 9100, max_shift=3)
-    monkeypatch.setenv("OFARN_DIRECT_MIN_FRAMES", "32")
-    with H.FarnebackEngine(160, 120, 20, levels=2) as eng:              # 40 frames in one wave: direct by default
+    monkeypatch.setenv("OFARN_DIRECT_MIN_FRAMES", "1000000")
+    with H.FarnebackEngine(160, 120, 20, levels=2) as eng:              # 40 frames in one wave through the row + column pass pair
         flow, _, _ = eng.calc_batch(frames, H.PAIRS_INDEPENDENT, want_danger=False)
     for i in (0, 7, 19):
         np.testing.assert_array_equal(flow[i], oracle.farneback(frames[2 * i], frames[2 * i + 1], levels=2, box_mode=oracle.BOX_BLOCKED))
@@ -800,7 +800,7 @@ def _fuzz_cases(n, seed):
 def test_fuzz_pipeline_bit_exact(H, oracle, iter_kernel, w, h, seed, kw, monkeypatch):
     """Random sizes and parameter sets (fused, generic, direct-level and flag paths all get hit): the whole pipeline
     bit for bit against the oracle in the device summation order."""
-    monkeypatch.setenv("OFARN_DIRECT_MIN_FRAMES", "1" if seed % 2 else "32")
+    monkeypatch.setenv("OFARN_DIRECT_MIN_FRAMES", "0" if seed % 2 else "1000000")
     if seed % 3 == 0:      # a third of the cases on the FPV-like warped family (non-uniform, sub-pixel flow + occluder)
         a, b, gt, _ = warped_pair(h, w, seed, zoom=1.0 + 0.01 * (seed % 5), angle_deg=(seed % 7) - 3.0)
         tx, ty = (float(v) for v in gt[h // 2, w // 2])
