@@ -5,6 +5,8 @@
 //                  OPTFLOW_USE_INITIAL_FLOW                                 optflowgf.cpp calc()
 //   k_flow_hsv     draw_hsv: direction -> hue, length -> value, HSV2BGR     DenseOF.py:109-124
 //   k_flow_arrows  draw_flow: step-14 sampling and int32 line end points    DenseOF.py:40-49
+//   k_draw_lamps   draw_sparse_lamps: a filled disc per danger point,        pathfinder_viewer.py:196-222
+//                  optionally cv2.add-ed onto the frame                      pathfinder_viewer.py:299-300
 //
 // All of them are HBM-bound byte/elementwise work; none is on the timed hot path of bench.py.
 #include "ofarn_internal.h"
@@ -259,6 +261,80 @@ void launch_flow_arrows(hipStream_t s, const float *flow, int w, int h, int npai
     if (n == 0) return;
     hipLaunchKernelGGL(k_flow_arrows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const float2 *>(flow), w, h, npairs, nx, ny, start, step, lines);
+}
+
+// ---------------------------------------------------------------------------------------------
+// draw_sparse_lamps (pathfinder_viewer.py:196-222) on the measurement grid: hsv[y, x] = (0, 255, V) at every danger point,
+// cvtColor(HSV2BGR) -> (0, 0, V), then cv2.circle(bgr, (x, y), radius, that colour, thickness=-1).  The discs of two grid points
+// never touch (the host checks step > 2 radius), so a pixel belongs to at most one point: the one whose column index is
+// floor((x - x0 + radius) / step).  ext[|dy|] is the half-width of the disc's row |dy| as cv2.circle's midpoint loop fills it.
+// With `base` the layer is added to it as cv2.add does (saturating; only the red channel can change).
+// One thread writes 4 pixels of the flattened batch: 12 bytes = three dwords when both images are dword-aligned.
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void k_draw_lamps(const uint8_t *__restrict__ mask, const uint8_t *__restrict__ v, int P,
+                                                    const uint8_t *__restrict__ base, uint8_t *__restrict__ out, int w, int h,
+                                                    size_t npx_total, LampGrid g)
+{
+    const size_t p0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p0 >= npx_total) return;
+    const size_t npx = (size_t)w * h;
+    const int cnt = npx_total - p0 < 4 ? (int)(npx_total - p0) : 4;
+    uint8_t px[12];
+    if (base) {
+        if (ALIGNED && cnt == 4) {
+            const uint32_t *b = reinterpret_cast<const uint32_t *>(base + p0 * 3);
+            const uint32_t b0 = b[0], b1 = b[1], b2 = b[2];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { px[k] = (uint8_t)(b0 >> (8 * k)); px[4 + k] = (uint8_t)(b1 >> (8 * k)); px[8 + k] = (uint8_t)(b2 >> (8 * k)); }
+        } else {
+            for (int k = 0; k < 12; k++) px[k] = k < cnt * 3 ? base[p0 * 3 + k] : 0;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; k++) px[k] = 0;
+    }
+    const int img = (int)(p0 / npx);
+    const int r0 = (int)(p0 % npx);
+    int y = r0 / w, x = r0 % w, im = img;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (k < cnt) {
+            const int ax = x - g.x0 + g.radius, ay = y - g.y0 + g.radius;
+            if (ax >= 0 && ay >= 0) {
+                const int i = ax / g.step, j = ay / g.step;
+                const int dx = ax - i * g.step - g.radius, dy = ay - j * g.step - g.radius;
+                const int ady = dy < 0 ? -dy : dy, adx = dx < 0 ? -dx : dx;
+                if (i < g.nx && j < g.ny && ady <= g.radius && adx <= (int)g.ext[ady]) {
+                    const size_t q = (size_t)im * P + (size_t)i * g.ny + j;       // grid order: x-major (pathfinder_viewer.py:263-266)
+                    if (mask[q]) {
+                        const int red = (int)px[3 * k + 2] + (int)v[q];
+                        px[3 * k + 2] = (uint8_t)(red > 255 ? 255 : red);
+                    }
+                }
+            }
+        }
+        if (++x == w) { x = 0; if (++y == h) { y = 0; im++; } }
+    }
+    if (ALIGNED && cnt == 4) {
+        uint32_t *o = reinterpret_cast<uint32_t *>(out + p0 * 3);
+        uint32_t o0 = 0, o1 = 0, o2 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { o0 |= (uint32_t)px[k] << (8 * k); o1 |= (uint32_t)px[4 + k] << (8 * k); o2 |= (uint32_t)px[8 + k] << (8 * k); }
+        o[0] = o0; o[1] = o1; o[2] = o2;
+    } else {
+        for (int k = 0; k < cnt * 3; k++) out[p0 * 3 + k] = px[k];
+    }
+}
+
+void launch_draw_lamps(hipStream_t s, const uint8_t *mask, const uint8_t *v, int P, const uint8_t *base, uint8_t *out, int w, int h,
+                       int n, const LampGrid &g)
+{
+    const size_t total = (size_t)n * w * h;
+    if (total == 0) return;
+    const dim3 grid((unsigned)((total + 1023) / 1024));
+    const bool aligned = (((uintptr_t)out | (uintptr_t)base) & 3) == 0;
+    if (aligned) hipLaunchKernelGGL(k_draw_lamps<true>, grid, dim3(256), 0, s, mask, v, P, base, out, w, h, total, g);
+    else hipLaunchKernelGGL(k_draw_lamps<false>, grid, dim3(256), 0, s, mask, v, P, base, out, w, h, total, g);
 }
 
 }  // namespace ofarn

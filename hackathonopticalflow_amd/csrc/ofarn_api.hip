@@ -781,7 +781,7 @@ void ofarn_destroy(ofarn_ctx *c)
         }
     }
     if (c->stream_state.R) (void)hipFree(c->stream_state.R);
-    for (uint8_t *p : {c->stream_state.d_frame, c->stream_state.d_bgr, c->stream_state.d_view}) if (p) (void)hipFree(p);
+    for (uint8_t *p : {c->stream_state.d_frame, c->stream_state.d_bgr, c->stream_state.d_view, c->stream_state.d_lamps}) if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev_level) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; i++) {
         if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }

@@ -15,6 +15,46 @@ int arrow_axis(int size, int step, double *start)
     return n < 0 ? 0 : n;
 }
 
+// cv2.circle(img, center, radius, color, thickness=-1) with LINE_8 and shift 0 runs drawing.cpp's Circle(): a midpoint loop that
+// fills the spans [cx - dx, cx + dx] on rows cy +- dy and [cx - dy, cx + dy] on rows cy +- dx.  ext[d] = the widest span half-width
+// any step gives row d (radius 6: 6 5 5 5 4 3 0).
+static void circle_extents(int radius, uint8_t *ext)
+{
+    for (int i = 0; i <= radius; i++) ext[i] = 0;
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        if (dx > ext[dy]) ext[dy] = (uint8_t)dx;
+        if (dy > ext[dx]) ext[dx] = (uint8_t)dy;
+        dy++;
+        err += plus;
+        plus += 2;
+        const int mask = (err <= 0) - 1;
+        err -= minus & mask;
+        dx += mask;
+        minus -= mask & 2;
+    }
+}
+
+int lamp_grid(const ofarn_ctx *c, int w, int h, int radius, ofarn::LampGrid *g, int *P)
+{
+    if (radius < 0 || radius > kMaxLampRadius) return fail(OFARN_E_INVALID, "lamp radius %d outside 0..%d", radius, kMaxLampRadius);
+    if (c->prm.grid_step <= 2 * radius)
+        return fail(OFARN_E_UNSUPPORTED, "discs of radius %d on a grid of step %d would overlap (the later disc then takes the colour "
+                    "under its centre, pathfinder_viewer.py:220-222): not built", radius, c->prm.grid_step);
+    std::vector<int> xs, ys;
+    axis_points(w, c->prm.grid_step, &xs);
+    axis_points(h, c->prm.grid_step, &ys);
+    g->x0 = xs.empty() ? 0 : xs[0];
+    g->y0 = ys.empty() ? 0 : ys[0];
+    g->step = c->prm.grid_step;
+    g->nx = (int)xs.size();
+    g->ny = (int)ys.size();
+    g->radius = radius;
+    circle_extents(radius, g->ext);
+    *P = g->nx * g->ny;
+    return OFARN_OK;
+}
+
 }  // namespace ofarn_host
 
 extern "C" {
@@ -100,6 +140,53 @@ int ofarn_hsv2bgr(ofarn_ctx *c, const uint8_t *h_hsv, size_t npx, uint8_t *h_bgr
     launch_hsv2bgr(c->stream, in.as<uint8_t>(), npx, out.as<uint8_t>());
     HIP_TRY(hipMemcpyAsync(h_bgr, out.p, npx * 3, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return OFARN_OK;
+}
+
+int ofarn_draw_lamps_device(ofarn_ctx *c, const uint8_t *d_mask, const uint8_t *d_v, int n, int w, int h, int radius,
+                            const uint8_t *d_base, uint8_t *d_out, void *hip_stream)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    if (!d_out) return fail(OFARN_E_INVALID, "out is NULL");
+    if (n < 0 || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad arguments n=%d %dx%d", n, w, h);
+    LampGrid g;
+    int P = 0;
+    int rc = lamp_grid(c, w, h, radius, &g, &P);
+    if (rc) return rc;
+    if (P > 0 && (!d_mask || !d_v)) return fail(OFARN_E_INVALID, "mask and v must not be NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    launch_draw_lamps(pick_stream(c, hip_stream), d_mask, d_v, P, d_base, d_out, w, h, n, g);
+    HIP_TRY(hipGetLastError());
+    return OFARN_OK;
+}
+
+int ofarn_draw_lamps(ofarn_ctx *c, const uint8_t *h_mask, const uint8_t *h_v, int n, int w, int h, int radius,
+                     const uint8_t *h_base, uint8_t *h_out)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    if (!h_out) return fail(OFARN_E_INVALID, "out is NULL");
+    if (n < 0 || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad arguments n=%d %dx%d", n, w, h);
+    LampGrid g;
+    int P = 0;
+    int rc = lamp_grid(c, w, h, radius, &g, &P);
+    if (rc) return rc;
+    if (P > 0 && (!h_mask || !h_v)) return fail(OFARN_E_INVALID, "mask and v must not be NULL");
+    if (n == 0) return OFARN_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t img = (size_t)w * h * 3;
+    DevTmp dm, base, out;
+    if ((rc = dm.alloc((size_t)2 * P + 16)) || (rc = out.alloc(img)) || (h_base && (rc = base.alloc(img)))) return rc;
+    for (int i = 0; i < n; i++) {
+        if (P > 0) {
+            HIP_TRY(hipMemcpyAsync(dm.p, h_mask + (size_t)i * P, P, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(dm.as<uint8_t>() + P, h_v + (size_t)i * P, P, hipMemcpyHostToDevice, c->stream));
+        }
+        if (h_base) HIP_TRY(hipMemcpyAsync(base.p, h_base + (size_t)i * img, img, hipMemcpyHostToDevice, c->stream));
+        launch_draw_lamps(c->stream, dm.as<uint8_t>(), dm.as<uint8_t>() + P, P, h_base ? base.as<uint8_t>() : nullptr, out.as<uint8_t>(),
+                          w, h, 1, g);
+        HIP_TRY(hipMemcpyAsync(h_out + (size_t)i * img, out.p, img, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     return OFARN_OK;
 }
 

@@ -72,6 +72,7 @@ int stream_turn(ofarn_ctx *c, hipStream_t s, const uint8_t *d_gray, int w, int h
     st.have = true;
     st.turns++;
     st.view_flow_valid = had && d_flow == c->st_flow && d_flow != nullptr;
+    st.view_danger_valid = st.view_bgr_valid = false;      // ofarn_stream_next_view sets them behind its own turn
     return had ? OFARN_OK : OFARN_STREAM_PRIMED;
 }
 
@@ -236,6 +237,7 @@ int ofarn_stream_next_view(ofarn_ctx *c, const uint8_t *h_frame, int bgr, int w,
     if (c->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW)
         return fail(OFARN_E_UNSUPPORTED, "ofarn_stream_next_view keeps the flow on the device and has no initial-flow input: use ofarn_stream_next");
     ofarn_ctx::Stream &st = c->stream_state;
+    st.view_danger_valid = st.view_bgr_valid = false;      // the buffers below may move
     const size_t fsz = (size_t)w * h;
     double astart = 0;
     const int nx = h_lines ? arrow_axis(w, arrow_step, &astart) : 0, ny = h_lines ? arrow_axis(h, arrow_step, &astart) : 0;
@@ -274,6 +276,12 @@ int ofarn_stream_next_view(ofarn_ctx *c, const uint8_t *h_frame, int bgr, int w,
         if (h_rainbow) launch_flow_hsv(s, c->st_flow, fsz, nullptr, d_rb);
         HIP_TRY(hipGetLastError());
     }
+    if (turn == OFARN_OK) {
+        st.view_danger_valid = P > 0;
+        st.view_mask_off = lines_bytes;
+        st.view_P = (int)P;
+        st.view_bgr_valid = bgr != 0;
+    }
     HIP_TRY(hipEventRecord(c->ev1, s));
     if (turn == OFARN_OK) {
         if (small) HIP_TRY(hipMemcpyAsync(st.h_view, st.d_view, small, hipMemcpyDeviceToHost, s));
@@ -304,6 +312,34 @@ int ofarn_stream_view_flow(ofarn_ctx *c, int w, int h, float *h_flow)
     HIP_TRY(hipMemcpyAsync(h_flow, c->st_flow, (size_t)w * h * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return end_call(c, c->stream);
+}
+
+// draw_sparse_lamps for the danger map of the most recent ofarn_stream_next_view turn, which is still on the device; with over_frame
+// the layer is cv2.add-ed onto the turn's BGR frame (pathfinder_viewer.py:299-300), which the turn uploaded anyway.
+int ofarn_stream_view_lamps(ofarn_ctx *c, int w, int h, int radius, int over_frame, uint8_t *h_out)
+{
+    if (!c || !h_out) return fail(OFARN_E_INVALID, "ctx or out is NULL");
+    ofarn_ctx::Stream &st = c->stream_state;
+    if (!(st.have && st.view_danger_valid && st.w == w && st.h == h) || !st.d_view)
+        return fail(OFARN_E_INVALID, "no ofarn_stream_next_view turn of %dx%d has produced a danger map on this context yet", w, h);
+    if (over_frame && !st.view_bgr_valid)
+        return fail(OFARN_E_INVALID, "over_frame needs the turn's frame in BGR, and the most recent view turn was given a gray frame");
+    LampGrid g;
+    int P = 0;
+    int rc = lamp_grid(c, w, h, radius, &g, &P);
+    if (rc) return rc;
+    if (P != st.view_P) return fail(OFARN_E_INVALID, "the turn's danger map has %d points, the grid of %dx%d has %d", st.view_P, w, h, P);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t img = (size_t)w * h * 3;
+    if ((rc = grow_u8(c, &st.d_lamps, &st.lamps_cap, img, "lamp layer"))) return rc;
+    hipStream_t s = c->stream;
+    if ((rc = begin_call(c, s))) return rc;
+    const uint8_t *d_mask = st.d_view + st.view_mask_off;
+    launch_draw_lamps(s, d_mask, d_mask + P, P, over_frame ? st.d_bgr : nullptr, st.d_lamps, w, h, 1, g);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_out, st.d_lamps, img, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return end_call(c, s);
 }
 
 // Pipelined submission: enqueue the turn and return; the flow lands in h_flow asynchronously (copy stream), while the caller

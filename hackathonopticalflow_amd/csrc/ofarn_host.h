@@ -124,6 +124,12 @@ struct ofarn_ctx {
         uint8_t *h_view = nullptr;      // page-locked landing zone of the small results (mask, v, lines): one transfer, then host copies
         size_t h_view_cap = 0;
         bool view_flow_valid = false;   // c->st_flow holds the flow of the most recent turn (ofarn_stream_next_view)
+        bool view_danger_valid = false; // d_view + view_mask_off holds mask[view_P], v[view_P] of the most recent turn (ofarn_stream_view_lamps)
+        bool view_bgr_valid = false;    // d_bgr holds the BGR frame of that turn
+        size_t view_mask_off = 0;
+        int view_P = 0;
+        uint8_t *d_lamps = nullptr;     // ofarn_stream_view_lamps: the lamp layer / composited frame on the device
+        size_t lamps_cap = 0;
         unsigned long long turns = 0;
         // pipelined submission (ofarn_stream_submit / ofarn_stream_wait): two device flow buffers used in turn, a copy stream whose
         // device-to-host transfer of turn t runs beside the kernels of turn t+1
@@ -183,8 +189,11 @@ inline hipStream_t pick_stream(const ofarn_ctx *c, void *hip_stream)
 
 // ofarn_api_extras.hip: np.mgrid[step/2:size:step] of draw_flow (DenseOF.py:44): count and float start
 int arrow_axis(int size, int step, double *start);
+// Lamp layer geometry for w x h frames on the context's measurement grid; OFARN_E_* if the discs would touch or the radius is out of range
+int lamp_grid(const ofarn_ctx *c, int w, int h, int radius, ofarn::LampGrid *g, int *P);
 // ofarn_api.hip
 int check_size(ofarn_ctx *c, int w, int h);
+int axis_points(int size, int step, std::vector<int> *out);   // the measurement grid along one axis (pathfinder_viewer.py:255-263)
 int make_plan(ofarn_ctx *c, int w, int h);
 int ensure_staging(ofarn_ctx *c, size_t frames_bytes, size_t flow_bytes, size_t dm_bytes);
 int build_area_tab(ofarn_ctx *c, int sw, int sh, int dw, int dh, ofarn::AreaTabHost &out);

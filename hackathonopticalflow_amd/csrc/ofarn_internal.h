@@ -133,6 +133,16 @@ void launch_hsv2bgr(hipStream_t s, const uint8_t *hsv, size_t npx, uint8_t *bgr)
 void launch_flow_arrows(hipStream_t s, const float *flow, int w, int h, int npairs, int nx, int ny, double start, double step,
                         int32_t *lines);
 
+// draw_sparse_lamps on the measurement grid: discs of `radius` at the grid points x0 + i step, y0 + j step whose mask is set
+// (point index i ny + j); ext[d] = half-width of the disc's row at distance d from the centre (cv2.circle's filled raster)
+constexpr int kMaxLampRadius = 31;
+struct LampGrid {
+    int x0, y0, step, nx, ny, radius;
+    uint8_t ext[kMaxLampRadius + 1];
+};
+void launch_draw_lamps(hipStream_t s, const uint8_t *mask, const uint8_t *v, int P, const uint8_t *base, uint8_t *out, int w, int h,
+                       int n, const LampGrid &g);
+
 // ---- sparse pyramidal Lucas-Kanade (kernels_lk.hip) ----
 void launch_pyrdown_u8(hipStream_t s, const uint8_t *src, int sw, int sh, uint8_t *dst, int nframes);
 void launch_scharr(hipStream_t s, const uint8_t *src, int w, int h, int16_t *dst, int z0, int zstep, int count);

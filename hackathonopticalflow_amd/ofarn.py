@@ -126,6 +126,10 @@ ABI = {
     "ofarn_stream_next_view": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_void_p]),
     "ofarn_stream_view_flow": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ofarn_stream_view_lamps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ofarn_draw_lamps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ofarn_draw_lamps_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
     "ofarn_stream_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ofarn_stream_wait": (C.c_int, [C.c_void_p, C.c_int]),
     "ofarn_stream_reset": (C.c_int, [C.c_void_p]),
@@ -541,6 +545,14 @@ class FarnebackEngine:
         _check(self._lib.ofarn_stream_view_flow(self._h, width, height, C.c_void_p(out.ctypes.data)))
         return out
 
+    def stream_view_lamps(self, width, height, radius=6, over_frame=False, out=None):
+        """draw_sparse_lamps for the danger map of the most recent stream_next_view turn (it stayed on the device): BGR
+        uint8[H,W,3]; over_frame: added onto the turn's BGR frame as pathfinder_viewer.py:299-300 does."""
+        o = out if (isinstance(out, np.ndarray) and out.dtype == np.uint8 and out.shape == (height, width, 3)
+                    and out.flags.c_contiguous) else np.empty((height, width, 3), np.uint8)
+        _check(self._lib.ofarn_stream_view_lamps(self._h, width, height, int(radius), 1 if over_frame else 0, C.c_void_p(o.ctypes.data)))
+        return o
+
     def stream_next_device(self, d_frame, width, height, d_flow=None, d_mask=None, d_v=None, stream=None, bgr=False) -> bool:
         """Device-resident turn (torch CUDA tensors or raw addresses), enqueued on `stream`, not synchronised.  Returns True when
         a flow / danger map was enqueued, False for the priming call."""
@@ -745,6 +757,37 @@ class FarnebackEngine:
         _check(self._lib.ofarn_flow_arrows(self._h, f.ctypes.data_as(_fp), n, w, h, int(step),
                                            lines.ctypes.data_as(C.POINTER(C.c_int32))))
         return lines[0] if single else lines
+
+    def draw_lamps(self, mask, v, shape, radius=6, base=None):
+        """draw_sparse_lamps (pathfinder_viewer.py:196-222) for danger maps on this engine's grid: mask, v uint8[P] (or [n,P]) as
+        calc_batch / danger_map return them, shape = (H, W) -> BGR uint8[H,W,3] (or [n,H,W,3]), black but for a filled disc of
+        colour (0, 0, V) per danger point.  base (same shape as the result): cv2.add(base, layer) instead (:299-300)."""
+        h, w = int(shape[0]), int(shape[1])
+        m = np.ascontiguousarray(mask, np.uint8)
+        vv = np.ascontiguousarray(v, np.uint8)
+        single = m.ndim == 1
+        if single:
+            m, vv = m[None], vv[None]
+        P = len(grid_points(w, h, self.params.grid_step))
+        if m.shape != vv.shape or m.ndim != 2 or m.shape[1] != P:
+            raise ValueError(f"mask and v must be uint8[{P}] or uint8[n,{P}] for {w}x{h} frames, got {m.shape} and {vv.shape}")
+        n = m.shape[0]
+        b = None
+        if base is not None:
+            b = np.ascontiguousarray(base, np.uint8).reshape(-1, h, w, 3) if np.size(base) == n * h * w * 3 else None
+            if b is None:
+                raise ValueError(f"base must be uint8[{'' if single else 'n,'}{h},{w},3]")
+        out = np.empty((n, h, w, 3), np.uint8)
+        _check(self._lib.ofarn_draw_lamps(self._h, C.c_void_p(m.ctypes.data), C.c_void_p(vv.ctypes.data), n, w, h, int(radius),
+                                          C.c_void_p(b.ctypes.data) if b is not None else None, C.c_void_p(out.ctypes.data)))
+        return out[0] if single else out
+
+    def draw_lamps_device(self, d_mask, d_v, n, width, height, d_out, radius=6, d_base=None, stream=None):
+        P = len(grid_points(width, height, self.params.grid_step))
+        npx = n * width * height
+        _check(self._lib.ofarn_draw_lamps_device(self._h, _ptr(d_mask, "d_mask", "uint8", n * P), _ptr(d_v, "d_v", "uint8", n * P), n,
+                                                 width, height, int(radius), _ptr(d_base, "d_base", "uint8", npx * 3),
+                                                 _ptr(d_out, "d_out", "uint8", npx * 3), _stream_arg(stream)))
 
     def danger_map_device(self, d_flow, n, width, height, d_mask, d_v, d_iflow=None, stream=None):
         P = len(grid_points(width, height, self.params.grid_step))
@@ -1031,6 +1074,14 @@ class FlowStream:
         h, w = self._shape
         return self._eng.stream_view_flow(w, h)
 
+    def view_lamps(self, radius=6, over_frame=False):
+        """The viewer's obstacle layer of the last next_view(danger=True) turn (draw_sparse_lamps, pathfinder_viewer.py:196-222),
+        BGR uint8[H,W,3]; over_frame=True: cv2.add-ed onto the turn's BGR frame (:299-300).  The array is reused by the next call."""
+        h, w = self._shape
+        if "lamps" not in self._view:
+            self._view["lamps"] = pinned_empty((h, w, 3), np.uint8)
+        return self._eng.stream_view_lamps(w, h, radius, over_frame, out=self._view["lamps"])
+
     def flush(self):
         """Pipelined mode: waits for the turn in flight and returns its flow (None if there is none)."""
         if not self._pending or self._eng is None:
@@ -1270,6 +1321,15 @@ def flow_lines(flow, step=14, device=0):
     f = np.asarray(flow)
     with _engine_for(f.shape[0], f.shape[1], device) as eng:
         return eng.flow_arrows(f, step)
+
+
+def draw_sparse_lamps(mask, v, shape, step=30, radius=6, base=None, device=0):
+    """pathfinder_viewer.py:196-222 ``draw_sparse_lamps`` for a danger map on the step-`step` grid of an (H, W) frame: the BGR
+    obstacle layer (optionally cv2.add-ed onto `base`, :299-300).  The reference passes the kept points and their int32 flow;
+    here they come as the (mask, v) pair that danger_map / calc_batch return for the same grid."""
+    h, w = int(shape[0]), int(shape[1])
+    with _engine_for(h, w, device, grid_step=int(step)) as eng:
+        return eng.draw_lamps(mask, v, (h, w), radius=radius, base=base)
 
 
 def danger_map(flow, step=30, device=0, filter_variant=FILTER_VIEWER, return_flow=False):

@@ -141,6 +141,11 @@ int ofarn_stream_next_device_bgr(ofarn_ctx *ctx, const uint8_t *d_bgr, int w, in
 int ofarn_stream_next_view(ofarn_ctx *ctx, const uint8_t *h_frame, int bgr, int w, int h, int stride, uint8_t *h_mask,
                            uint8_t *h_v, int arrow_step, int32_t *h_lines, uint8_t *h_rainbow);
 int ofarn_stream_view_flow(ofarn_ctx *ctx, int w, int h, float *h_flow);
+/* The viewer's obstacle layer of that turn (draw_sparse_lamps, see ofarn_draw_lamps below) from the danger map the turn left on the
+ * device: h_out uint8[h][w][3] BGR.  over_frame != 0: the layer added onto the turn's own BGR frame -- output_bgr =
+ * cv2.add(output_bgr, draw_sparse_lamps(...)), pathfinder_viewer.py:299-300 -- which the turn had uploaded anyway (needs bgr != 0
+ * and h_mask / h_v in that ofarn_stream_next_view call). */
+int ofarn_stream_view_lamps(ofarn_ctx *ctx, int w, int h, int radius, int over_frame, uint8_t *h_out);
 /* Pipelined form for throughput: ofarn_stream_submit enqueues the turn (upload, kernels, transfer of the flow into h_flow on a copy
  * stream) and returns without waiting; the caller submits the next frame at once, whose kernels then run BESIDE this turn's
  * device-to-host transfer (at 1080p the 16.6 MB of flow take about as long over PCIe as the kernels).  h_flow of a turn is complete
@@ -190,6 +195,17 @@ int ofarn_flow_arrow_count(int w, int h, int step, int *nx, int *ny);
 int ofarn_flow_arrows(ofarn_ctx *ctx, const float *h_flow, int n, int w, int h, int step, int32_t *h_lines);
 int ofarn_flow_arrows_device(ofarn_ctx *ctx, const float *d_flow, int n, int w, int h, int step,
                              int32_t *d_lines, void *hip_stream);
+
+/* draw_sparse_lamps (pathfinder_viewer.py:196-222) for danger maps on the context's measurement grid: a BGR layer uint8[n][h][w][3]
+ * that is black except for one filled disc per danger point (mask != 0) -- hsv[y, x] = (0, 255, V), cv2.cvtColor(HSV2BGR) = (0, 0, V),
+ * cv2.circle(bgr, (x, y), radius, that colour, thickness=-1) in drawing.cpp's LINE_8 raster; the reference's radius is 6.  mask, v:
+ * uint8[n][P] as ofarn_calc_batch / ofarn_grid_filter return them.  base (uint8[n][h][w][3], or NULL): the layer is added onto it
+ * with saturation, cv2.add(output_bgr, layer) of pathfinder_viewer.py:299-300.  The grid step must exceed 2 * radius (discs that
+ * touch would take the colour under their centre: OFARN_E_UNSUPPORTED); radius 0..31. */
+int ofarn_draw_lamps(ofarn_ctx *ctx, const uint8_t *h_mask, const uint8_t *h_v, int n, int w, int h, int radius,
+                     const uint8_t *h_base, uint8_t *h_out);
+int ofarn_draw_lamps_device(ofarn_ctx *ctx, const uint8_t *d_mask, const uint8_t *d_v, int n, int w, int h, int radius,
+                            const uint8_t *d_base, uint8_t *d_out, void *hip_stream);
 
 /* ---- sparse pyramidal Lucas-Kanade -----------------------------------------
  * cv2.calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts, winSize, maxLevel, criteria, flags,

@@ -470,6 +470,57 @@ def draw_hsv_numpy(flow_, cr=True):
     return hsv2bgr_u8(draw_hsv_planes_numpy(flow_, cr=cr))
 
 
+def cv_circle_filled(img, center, radius, color):
+    """cv2.circle(img, center, radius, color, thickness=-1), lineType LINE_8, shift 0: drawing.cpp Circle() -- a midpoint loop that
+    fills the spans [cx-dx, cx+dx] on rows cy+-dy and [cx-dy, cx+dy] on rows cy+-dx, clipped to the image.  In place."""
+    h, w = img.shape[:2]
+    cx, cy = int(center[0]), int(center[1])
+
+    def hline(y, x1, x2):
+        if 0 <= y < h:
+            x1, x2 = max(x1, 0), min(x2, w - 1)
+            if x1 <= x2:
+                img[y, x1:x2 + 1] = color
+
+    err, dx, dy, plus, minus = 0, int(radius), 0, 1, (int(radius) << 1) - 1
+    while dx >= dy:
+        hline(cy - dy, cx - dx, cx + dx)
+        hline(cy + dy, cx - dx, cx + dx)
+        hline(cy - dx, cx - dy, cx + dy)
+        hline(cy + dx, cx - dy, cx + dy)
+        dy += 1
+        err += plus
+        plus += 2
+        mask = (1 if err <= 0 else 0) - 1
+        err -= minus & mask
+        dx += mask
+        minus -= mask & 2
+
+
+def draw_sparse_lamps_numpy(flow_, points_, width, height, radius=6):
+    """draw_sparse_lamps (pathfinder_viewer.py:196-222), re-typed: NumPy lines by the real NumPy, HSV2BGR and cv2.circle by the
+    restatements above.  flow_, points_: the kept int32 vectors and points get_flow_lk returns (:175-176)."""
+    fx, fy = flow_[:, 0], flow_[:, 1]
+    ang = np.arctan2(fy, fx) + np.pi
+    modulus = np.sqrt(fx * fx + fy * fy)
+
+    hsv = np.zeros((height, width, 3), np.uint8)
+    for (x, y), a, m in zip(points_, ang, modulus):
+        hsv[y, x, 0] = 0
+        hsv[y, x, 1] = 255
+        hsv[y, x, 2] = np.minimum(50 + m * 2, 255)
+
+    bgr = hsv2bgr_u8(hsv)
+    for x, y, in points_:
+        cv_circle_filled(bgr, (x, y), radius, (int(bgr[y, x, 0]), int(bgr[y, x, 1]), int(bgr[y, x, 2])))
+    return bgr
+
+
+def cv_add_u8(a, b):
+    """cv2.add on uint8 arrays: saturating (pathfinder_viewer.py:299-300)."""
+    return np.minimum(a.astype(np.uint16) + b.astype(np.uint16), 255).astype(np.uint8)
+
+
 def draw_flow_lines_numpy(img_shape, flow, step=14):
     """DenseOF.py:40-49, re-typed: the int32 `lines` array handed to cv2.polylines."""
     h, w = img_shape

@@ -603,6 +603,60 @@ def test_draw_flow_lines_bit_exact(H, oracle, h, w, step):
     np.testing.assert_array_equal(got, ref)
 
 
+@pytest.mark.parametrize("h,w,step,radius", [(270, 480, 30, 6), (1080, 1920, 30, 6), (92, 100, 30, 6), (61, 75, 20, 9), (48, 64, 7, 3),
+                                              (40, 90, 30, 0), (70, 130, 64, 31), (20, 20, 30, 6)])
+def test_draw_sparse_lamps_bit_exact(H, oracle, h, w, step, radius):
+    """The viewer's obstacle layer (pathfinder_viewer.py:196-222): every kept point of the danger map becomes a filled disc of colour
+    (0, 0, V).  Reference side: the function's own NumPy lines on the kept int32 vectors and points, with cv2.cvtColor(HSV2BGR) and
+    cv2.circle restated (parity unpinned, as everything OpenCV here); 92 x 100 and 70 x 130 clip discs at the image border."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(h * w + radius)
+    flow = (rng.standard_normal((h, w, 2)) * rng.uniform(1, 40)).astype(np.float32)
+    if len(oracle.grid_points_numpy(w, h, step)):
+        mask, v, iflow = oracle.danger_map_numpy(flow, w, h, step, return_flow=True)
+    else:                                                          # 20 x 20: no grid point fits, the layer is black
+        mask, v, iflow = np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros((0, 2), np.int32)
+    if len(mask) and not mask.any():
+        mask[::2] = 1                                              # the filter kept nothing on this field: draw something anyway
+        v[::2] = oracle.lamp_values_numpy(iflow[::2])
+    pts = np.int32(oracle.grid_points_numpy(w, h, step) + 0.5)     # pathfinder_viewer.py:166
+    keep = mask.astype(bool)
+    ref = oracle.draw_sparse_lamps_numpy(iflow[keep], pts[keep], w, h, radius)
+    got = H.draw_sparse_lamps(mask, v, (h, w), step=step, radius=radius)
+    assert got.dtype == np.uint8 and got.shape == (h, w, 3)
+    np.testing.assert_array_equal(got, ref)
+    if keep.any():
+        assert int(got[..., 2].max()) == int(v[keep].max()) and not got[..., :2].any()
+    # cv2.add(output_bgr, layer) (pathfinder_viewer.py:299-300), as a stack of two frames
+    base = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+    with H.FarnebackEngine(w, h, 1, grid_step=step) as eng:
+        both = eng.draw_lamps(np.stack([mask, mask[::-1]]), np.stack([v, v[::-1]]), (h, w), radius=radius, base=base)
+        np.testing.assert_array_equal(both[0], oracle.cv_add_u8(base[0], ref))
+        ref1 = oracle.draw_sparse_lamps_numpy(iflow[::-1][keep[::-1]], pts[keep[::-1]], w, h, radius)
+        np.testing.assert_array_equal(both[1], oracle.cv_add_u8(base[1], ref1))
+        # device-resident, unaligned output address (byte path)
+        d_m, d_v = torch.from_numpy(mask).cuda(), torch.from_numpy(v).cuda()
+        d_out = torch.zeros(h * w * 3 + 1, dtype=torch.uint8, device="cuda")
+        eng.draw_lamps_device(d_m, d_v, 1, w, h, d_out[1:], radius=radius)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(d_out[1:].cpu().numpy().reshape(h, w, 3), ref)
+
+
+def test_draw_sparse_lamps_errors(H):
+    with H.FarnebackEngine(64, 48, 1, grid_step=12) as eng:
+        P = len(H.grid_points(64, 48, 12))
+        z = np.zeros(P, np.uint8)
+        with pytest.raises(NotImplementedError):
+            eng.draw_lamps(z, z, (48, 64), radius=6)                # discs of radius 6 touch on a step-12 grid
+        with pytest.raises(ValueError):
+            eng.draw_lamps(z, z, (48, 64), radius=32)
+        with pytest.raises(ValueError):
+            eng.draw_lamps(z[:-1], z[:-1], (48, 64), radius=2)
+        with pytest.raises(ValueError):
+            eng.draw_lamps(z, z, (48, 64), radius=2, base=np.zeros((48, 64), np.uint8))
+        assert not eng.draw_lamps(z, z, (48, 64), radius=5).any()
+
+
 # ------------------------------------------------------------------------------------ SURVEY 8(f): sparse pyramidal LK
 @pytest.mark.parametrize("h,w", [(37, 53), (270, 481), (1, 7), (6, 1), (1080, 1920)])
 def test_lk_pyrdown_and_scharr_bit_exact(H, oracle, h, w):

@@ -380,6 +380,14 @@ def test_view_turn_returns_what_the_viewer_draws(H, oracle):
             np.testing.assert_array_equal(res["v"], v)
             np.testing.assert_array_equal(res["lines"], eng.flow_arrows(flow, 14))
             np.testing.assert_array_equal(res["rainbow"], eng.flow_hsv(flow))
+            # the obstacle layer of the same turn, alone and added onto the turn's own frame (pathfinder_viewer.py:299-300)
+            layer = eng.draw_lamps(mask, v, (h, w))
+            np.testing.assert_array_equal(st.view_lamps(), layer)
+            if i % 2 == 0:
+                np.testing.assert_array_equal(st.view_lamps(over_frame=True), oracle.cv_add_u8(bgr[i], layer))
+            else:
+                with pytest.raises(ValueError):
+                    st.view_lamps(over_frame=True)                  # the turn's frame was gray
         # only the danger map; then an ordinary turn continues the session, after which the device no longer holds a view flow
         res = st.next_view(fr[0], arrows=None)
         assert set(res) >= {"mask", "v"}
@@ -387,6 +395,8 @@ def test_view_turn_returns_what_the_viewer_draws(H, oracle):
         np.testing.assert_array_equal(st.next(fr[1]), eng.calc(fr[0], fr[1]))
         with pytest.raises(ValueError):
             st.view_flow()
+        with pytest.raises(ValueError):
+            st.view_lamps()
     with H.FarnebackEngine(w, h, 1, levels=3, flags=4) as eng:
         with pytest.raises(NotImplementedError):
             eng.stream_next_view(fr[0])

@@ -160,3 +160,35 @@ def test_initial_flow_coarsest_level_is_scaled_area_resize(oracle):
         oracle.farneback(a, b, levels=1, flags=4)
     with pytest.raises(ValueError):
         oracle.farneback(a, b, flags=8)
+
+
+def test_cv_circle_filled_shape_and_clipping(oracle):
+    """cv2.circle's filled LINE_8 raster as restated: radius 6 has rows of half-width 6 5 5 5 4 3 0 (the one-pixel tips of small OpenCV
+    discs), is symmetric, lies inside the Euclidean disc of radius r + 0.5 and clips at the image border."""
+    img = np.zeros((15, 15), np.uint8)
+    oracle.cv_circle_filled(img, (7, 7), 6, 1)
+    half = [int(img[7 + d].sum() - 1) // 2 for d in range(7)]
+    assert half == [6, 5, 5, 5, 4, 3, 0]
+    np.testing.assert_array_equal(img, img[::-1])
+    np.testing.assert_array_equal(img, img.T)
+    for r in range(0, 32):
+        big = np.zeros((2 * r + 5, 2 * r + 5), np.uint8)
+        c = r + 2
+        oracle.cv_circle_filled(big, (c, c), r, 1)
+        yy, xx = np.nonzero(big)
+        assert ((yy - c) ** 2 + (xx - c) ** 2 <= (r + 0.5) ** 2 + 1e-9).all()
+        assert big[c, c - r] == 1 and big[c - r, c] == 1 and big.sum() >= 0.75 * np.pi * r * r
+        # clipped: the same disc drawn partly outside equals the crop of the whole one
+        crop = np.zeros((r + 3, r + 4), np.uint8)
+        oracle.cv_circle_filled(crop, (1, 2), r, 1)
+        np.testing.assert_array_equal(crop, big[c - 2:c - 2 + r + 3, c - 1:c - 1 + r + 4])
+
+
+def test_draw_sparse_lamps_numpy_known_case(oracle):
+    flow = np.array([[3, 4], [0, 0], [200, 0]], np.int32)        # |f| = 5 -> V = 60; 0 -> 50; 200 -> 255 (saturated)
+    pts = np.array([[10, 10], [40, 10], [70, 10]], np.int32)
+    bgr = oracle.draw_sparse_lamps_numpy(flow, pts, 90, 30)
+    assert bgr[10, 10].tolist() == [0, 0, 60] and bgr[10, 16].tolist() == [0, 0, 60] and bgr[10, 17].tolist() == [0, 0, 0]
+    assert bgr[10, 40].tolist() == [0, 0, 50] and bgr[4, 70].tolist() == [0, 0, 255] and bgr[3, 70].tolist() == [0, 0, 0]
+    assert int((bgr[..., 2] > 0).sum()) == 3 * int((bgr[..., 2] == 60).sum())
+    np.testing.assert_array_equal(oracle.cv_add_u8(np.full_like(bgr, 250), bgr)[10, 10], [250, 250, 255])
