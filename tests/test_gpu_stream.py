@@ -400,3 +400,42 @@ def test_view_turn_returns_what_the_viewer_draws(H, oracle):
     with H.FarnebackEngine(w, h, 1, levels=3, flags=4) as eng:
         with pytest.raises(NotImplementedError):
             eng.stream_next_view(fr[0])
+
+
+def test_dropin_results_come_from_a_pinned_pool_and_are_never_recycled_while_referenced(H):
+    """cv2 returns a new array per call; the drop-in returns views of page-locked blocks (the last kernel writes them directly) that
+    go back to a pool only when the caller has dropped the array AND every view of it.  A caller who keeps results gets at most
+    four such blocks per frame size, plain arrays beyond that -- and always the right values."""
+    import gc
+    w, h = 160, 120
+    fr = video(8, h, w, 77)
+    H.close_cached_engines()
+    kept = [H.calculate_optical_flow(fr[i], fr[i + 1]) for i in range(7)]
+    assert len({k.ctypes.data for k in kept}) == 7
+    with H.FarnebackEngine(w, h, 1) as eng:
+        for i, k in enumerate(kept):
+            assert k.dtype == np.float32 and k.shape == (h, w, 2) and k.flags.c_contiguous and k.flags.writeable
+            np.testing.assert_array_equal(k, eng.calc(fr[i], fr[i + 1]))
+        a0 = kept[0].ctypes.data
+        snapshot, view = kept[0].copy(), kept[0][:, :, 0]
+        del kept[0]
+        gc.collect()
+        f = H.calculate_optical_flow(fr[0], fr[1])                 # the first block is still referenced through `view`
+        fa = f.ctypes.data
+        assert fa != a0
+        np.testing.assert_array_equal(view, snapshot[:, :, 0])
+        np.testing.assert_array_equal(f, snapshot)
+        f[0, 0] = 7                                                # an ordinary writable array
+        del view, f
+        gc.collect()
+        g = H.calculate_optical_flow(fr[2], fr[3])
+        assert g.ctypes.data in (a0, fa)                           # a block the caller has let go of is used again
+        np.testing.assert_array_equal(g, eng.calc(fr[2], fr[3]))
+        # the loop as the reference writes it: the result is rebound every turn, so two blocks alternate
+        seen, prev = set(), fr[0]
+        for i in range(1, 8):
+            flow = H.calculate_optical_flow(prev, fr[i])
+            seen.add(flow.ctypes.data)
+            np.testing.assert_array_equal(flow, eng.calc(fr[i - 1], fr[i]))
+            prev = fr[i]
+        assert len(seen) <= 2
