@@ -229,7 +229,7 @@ def test_multi_gpu_entry_points_without_a_gpu():
 
 def test_drop_in_frame_reuse_bookkeeping():
     """The drop-in's reuse rule without a GPU: a slot "holds" a frame only if it is the SAME array object as the last call's `next`
-    and its fingerprint (address, shape, strides, checksum of every 8th row) is unchanged; an in-place change to a sampled row, a
+    and its fingerprint (address, shape, strides, checksum of every 16th row) is unchanged; an in-place change to a sampled row, a
     copy, a view, a dead reference or a non-array are all "not held"."""
     slot = ofarn._Slot(eng=None)
     a = np.random.default_rng(0).integers(0, 256, (120, 160)).astype(np.uint8)
@@ -237,10 +237,17 @@ def test_drop_in_frame_reuse_bookkeeping():
     slot.remember(a)
     assert slot.holds(a)
     assert not slot.holds(a.copy()) and not slot.holds(a[:]) and not slot.holds(a.tolist())
-    a[8, 5] ^= 1                          # row 8 is sampled
+    a[16, 5] ^= 1                         # row 16 is sampled
     assert not slot.holds(a)
-    a[8, 5] ^= 1
+    a[16, 5] ^= 1
     assert slot.holds(a)
+    odd = a[:, 1:]                        # rows that cannot be read as 64-bit words: byte sums
+    slot.remember(odd)
+    assert slot.holds(odd)
+    odd[32, 0] ^= 1
+    assert not slot.holds(odd)
+    odd[32, 0] ^= 1
+    slot.remember(a)
     b = a.copy()
     slot.remember(b)
     assert slot.holds(b) and not slot.holds(a)
