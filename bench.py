@@ -641,6 +641,8 @@ def main():
             "survey_8d_bytes_per_launch": survey_launch,
             "survey_8d_achieved": round(survey_launch / per_launch_s / 1e9, 1),
             "survey_8d_frac": round(survey_launch / per_launch_s / 1e9 / HBM_PEAK_GBS, 4),
+            "survey_8d_note": "work rate, not a bandwidth: SURVEY 8(d) prices the launch at 96 B/px including 40 B/px of M traffic "
+                              "that the fused kernel never moves, so it can exceed 1; `frac` (56 B/px) and `traffic_frac` (PMC) are the bandwidths",
             "pipeline": {
                 "algorithmic_bytes_per_pair": alg_pair,
                 "achieved": round(alg_pair * value / world / 1e9, 1),
