@@ -459,6 +459,16 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
             });
         init_cur = ws.flowA;
     }
+    // With the overlap the level loop runs twice: first every level's stages A + B go to the internal stream (so that stream
+    // can run ahead however the two streams share hardware queues), then the iteration chain to the caller's.  sync_at[k]: the
+    // chain waits for an event recorded behind level k's expansion ("stream_overlap" 1: behind every level's; 2: only behind the
+    // coarsest level's, then behind every second one's -- a wait for work that finished long ago costs the chain less than one
+    // for work that finishes just then, and by the time the chain has iterated a level the other stream is two levels ahead).
+    bool sync_at[32];
+    for (int k = 0; k <= nlev; k++) sync_at[k] = c->stream_overlap != 2 || k == nlev || k == 0 || ((nlev - k) % 2 == 1);
+    int waited = nlev + 1;           // the chain has waited for the event behind this level (and so for every level above it)
+    const int npass = overlap ? 2 : 1;
+    for (int pass = 0; pass < npass; pass++)
     for (int k = nlev; k >= 0; k--) {
         const Level &L = c->lv[k];
         const size_t npx = (size_t)L.w * L.h;
@@ -467,7 +477,15 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
         // stages A + B: level image and polynomial expansion of every frame of the wave
         const bool march = !c->force_generic && polyexp_march_supported(c->prm.poly_n);
         const bool lds_ok = (size_t)(w + 2 * (L.ksize / 2)) * 4 * 33 / 32 + 4 * (size_t)L.ksize + 64 <= 60 * 1024;
-        if (march && L.w == w && L.h == h && L.ksize == 3) {
+        if (overlap && pass == 1) {
+            // the chain: wait for the event that covers this level -- the nearest one recorded at or below it
+            if (iterate && waited > k) {
+                int e = k;
+                while (!sync_at[e]) e--;             // sync_at[0] is always set
+                HIP_TRY(hipStreamWaitEvent(s, c->ev_level[e], 0));
+                waited = e;
+            }
+        } else if (march && L.w == w && L.h == h && L.ksize == 3) {
             // scale 1: 3-tap blur fused into the polynomial expansion, frames read directly
             timed(c, sab, OFARN_STAGE_POLYEXP, k, ufr, [&] {
                 launch_polyexp_march(sab, d_frames, fsz, 1, R_ab(k), L.w, L.h, nframes, c->poly, L.h_kern3);
@@ -500,9 +518,9 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
             });
         }
         if (!iterate) continue;      // streaming, first frame: nothing to pair it with yet
-        if (overlap) {
-            HIP_TRY(hipEventRecord(c->ev_level[k], sab));
-            HIP_TRY(hipStreamWaitEvent(s, c->ev_level[k], 0));
+        if (overlap && pass == 0) {
+            if (sync_at[k]) HIP_TRY(hipEventRecord(c->ev_level[k], sab));
+            continue;
         }
         if (fused) {
             // stages (E +) C + D fused per iteration; flow ping-pongs between two buffers, the last
@@ -810,7 +828,7 @@ int ofarn_set_option(ofarn_ctx *c, const char *name, int value)
     else if (n == "direct_min_frames") c->direct_min_frames = value;
     else if (n == "single_stream") c->dual = value == 0;
     else if (n == "stream_zero_copy") c->stream_zero_copy = value != 0;
-    else if (n == "stream_overlap") c->stream_overlap = value != 0;
+    else if (n == "stream_overlap") c->stream_overlap = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "push_blocks") c->push_blocks = value < 0 ? 0 : value;
     else if (n == "debug_fail_wave") c->debug_fail_wave = value;
     else return fail(OFARN_E_INVALID, "unknown option '%s'", name);

@@ -148,7 +148,8 @@ struct ofarn_ctx {
         bool uploaded_valid[2] = {false, false};
         unsigned long long stages = 0;
     } stream_state;
-    int stream_overlap = 1;             // streaming turn: stages A + B on an internal stream beside the iteration chain (run_wave)
+    int stream_overlap = 2;             // streaming turn: stages A + B on an internal stream beside the iteration chain (run_wave);
+                                        // 1: the chain waits behind every level's expansion, 2: behind the coarsest and every second one
     hipEvent_t ev_level[32] = {nullptr};
     int push_blocks = 0;                // ofarn_stream_submit: > 0 pushes a finished flow field to pinned host memory with a kernel of that many
                                         // blocks instead of hipMemcpyAsync ("push_blocks"; measured slower at every size, kept as an experiment)

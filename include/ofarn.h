@@ -305,7 +305,8 @@ int ofarn_reserve(ofarn_ctx *ctx, int w, int h, int n_pairs, int pairs_mode);
  * ofarn_create.  name: "tile" (-1 choose by grid size / 0 never / 1 always use the tile iteration kernel; OFARN_TILE),
  * "force_generic" (OFARN_FORCE_GENERIC), "row_ltr" (OFARN_ROW_LTR), "direct_min_frames" (OFARN_DIRECT_MIN_FRAMES),
  * "single_stream" (OFARN_SINGLE_STREAM), "stream_zero_copy" (OFARN_STREAM_ZERO_COPY), "stream_overlap" (streaming turn: level
- * build + polynomial expansion on an internal stream beside the iteration chain; default 1), "push_blocks" (experiment, default 0 = hipMemcpyAsync: ofarn_stream_submit pushes a flow field to page-locked host memory with a
+ * build + polynomial expansion on an internal stream beside the iteration chain; 0 off, 1 the chain waits for an event behind every
+ * level's expansion, 2 = default: behind the coarsest level's and then every second one's), "push_blocks" (experiment, default 0 = hipMemcpyAsync: ofarn_stream_submit pushes a flow field to page-locked host memory with a
  * kernel of that many blocks), "debug_fail_wave" (test hook: the
  * (value+1)-th wave from now fails with OFARN_E_NOMEM; -1 = off). */
 int ofarn_set_option(ofarn_ctx *ctx, const char *name, int value);

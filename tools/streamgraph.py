@@ -24,7 +24,7 @@ def main():
     flow = torch.empty((h, w, 2), dtype=torch.float32, device="cuda")
     side = torch.cuda.Stream()
     st = side.cuda_stream
-    for overlap in (1, 0):
+    for overlap in (1, 2, 0, 2, 1):
         eng = ofa.FarnebackEngine(w, h, 1, 0, levels=5)
         eng.set_option("stream_overlap", overlap)
         with torch.cuda.stream(side):
