@@ -465,7 +465,7 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
     // coarsest level's, then behind every second one's -- a wait for work that finished long ago costs the chain less than one
     // for work that finishes just then, and by the time the chain has iterated a level the other stream is two levels ahead).
     bool sync_at[32];
-    for (int k = 0; k <= nlev; k++) sync_at[k] = c->stream_overlap != 2 || k == nlev || k == 0 || ((nlev - k) % 2 == 1);
+    for (int k = 0; k <= nlev; k++) sync_at[k] = c->stream_overlap < 2 || k == nlev || k == 0 || ((nlev - k) % 2 == 1);
     int waited = nlev + 1;           // the chain has waited for the event behind this level (and so for every level above it)
     const int npass = overlap ? 2 : 1;
     for (int pass = 0; pass < npass; pass++)
