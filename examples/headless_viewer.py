@@ -93,17 +93,19 @@ def run_loop(frames_bgr, device=0, step=30):
 
 
 def run_loop_view(frames_bgr, device=0, step=30):
-    """The loop again, taking per frame only what the viewers DRAW (danger map, draw_flow's arrow lines): FlowStream.next_view keeps
-    the 16.6 MB flow field on the device.  Returns (masks, vs, lines)."""
+    """The loop again, taking per frame only what the viewers DRAW (danger map, draw_flow's arrow lines, the obstacle layer added
+    onto the frame as pathfinder_viewer.py:299-300 does): FlowStream.next_view keeps the 16.6 MB flow field on the device.
+    Returns (masks, vs, lines, composited frames)."""
     import hackathonopticalflow_amd as ofa
-    masks, vs, lines = [], [], []
+    masks, vs, lines, shown = [], [], [], []
     with ofa.FlowStream(device=device, grid_step=step) as stream:
         for img in frames_bgr:
             view = stream.next_view(img, danger=True, arrows=14)
             if view is None:
                 continue
             masks.append(view["mask"].copy()); vs.append(view["v"].copy()); lines.append(view["lines"].copy())
-    return np.stack(masks), np.stack(vs), np.stack(lines)
+            shown.append(stream.view_lamps(over_frame=True).copy())       # output_bgr = cv2.add(img, draw_sparse_lamps(...))
+    return np.stack(masks), np.stack(vs), np.stack(lines), np.stack(shown)
 
 
 def main():
@@ -116,9 +118,10 @@ def main():
     out = run(video)
     _, loop_masks, _ = run_loop(video)
     print("frame loop (FlowStream) and batch danger masks identical:", bool((loop_masks == out["dense_mask"]).all()))
-    view_masks, _, view_lines = run_loop_view(video)
+    view_masks, _, view_lines, shown = run_loop_view(video)
     print("view loop (flow stays on the GPU): masks identical:", bool((view_masks == out["dense_mask"]).all()),
-          " arrow lines identical:", bool((view_lines == out["lines"]).all()))
+          " arrow lines identical:", bool((view_lines == out["lines"]).all()),
+          " pixels the obstacle layer changed per frame:", [int((shown[i] != video[i + 1]).any(-1).sum()) for i in range(len(shown))])
     for i in range(a.frames - 1):
         print(f"pair {i}: mean dense flow {out['mean_flow'][i].round(3)}  danger points dense {int(out['dense_mask'][i].sum())}"
               f" / LK {int(out['lk_mask'][i].sum())} of {len(out['points'])}  LK tracked {int(out['lk_status'][i].sum())}")

@@ -787,7 +787,7 @@ def test_lk_1080p_grid(H, oracle):
 
 
 # ------------------------------------------------------------------------------------ the viewers' frame loop, headless
-def test_headless_viewer_example(H):
+def test_headless_viewer_example(H, oracle):
     pytest.importorskip("torch")
     import importlib.util
     spec = importlib.util.spec_from_file_location(
@@ -807,10 +807,18 @@ def test_headless_viewer_example(H):
     np.testing.assert_array_equal(masks, out["dense_mask"])
     np.testing.assert_array_equal(vs, out["dense_v"])
     assert np.abs(flows.mean(axis=(1, 2)) - out["mean_flow"]).max() < 1e-4
-    vm, vv, vl = mod.run_loop_view(frames)
+    vm, vv, vl, shown = mod.run_loop_view(frames)
     np.testing.assert_array_equal(vm, out["dense_mask"])
     np.testing.assert_array_equal(vv, out["dense_v"])
     np.testing.assert_array_equal(vl, out["lines"])
+    # the composited frame: the obstacle layer of each pair added onto the later frame (pathfinder_viewer.py:299-300)
+    pts = np.int32(out["points"] + 0.5)
+    for i in range(4):
+        keep = out["dense_mask"][i].astype(bool)
+        layer = np.zeros((240, 320, 3), np.uint8)
+        for (x, y), val in zip(pts[keep], out["dense_v"][i][keep]):
+            oracle.cv_circle_filled(layer, (x, y), 6, (0, 0, int(val)))
+        np.testing.assert_array_equal(shown[i], oracle.cv_add_u8(frames[i + 1], layer))
 
 
 def test_lk_batch_points_per_pair_and_forward_direction(H, oracle):
