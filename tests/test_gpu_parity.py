@@ -213,6 +213,19 @@ def test_pipeline_4k_L6_I5_config5(H, oracle):
     assert gt.mean() < 0.1
 
 
+@pytest.mark.parametrize("w,h,levels,iterations", [(7680, 4320, 7, 3), (4097, 2161, 6, 3), (8191, 33, 3, 2), (33, 8191, 3, 2)])
+def test_beyond_baseline_sizes(H, oracle, w, h, levels, iterations):
+    """Past BASELINE's largest shape: an 8K pair with 8 scales (rows of 7680 no longer fit the row-pass kernels' LDS staging at the
+    coarse levels' tap counts), odd 4K-plus sizes (no level is an exact half), frames of 33 rows or columns (cropped to one scale).
+    Bit-exact against the oracle in the device's summation order, like every other size."""
+    a, b, (tx, ty) = translated_pair(h, w, 5, max_shift=6)
+    with H.FarnebackEngine(w, h, 1, levels=levels, iterations=iterations) as eng:
+        got = eng.calc(a, b)
+    np.testing.assert_array_equal(got, oracle.farneback(a, b, levels=levels, iterations=iterations, box_mode=oracle.BOX_BLOCKED))
+    if min(w, h) > 1000:
+        assert epe(got[64:-64, 64:-64], np.float32([tx, ty])[None, None]).mean() < 0.1
+
+
 def test_full_size_properties_config3(H):
     """Size-independent properties at BASELINE's full size (batch of 1080p pairs, levels=5):
     a pair and its duplicate in the same batch give identical flow and danger maps; the interior flow
