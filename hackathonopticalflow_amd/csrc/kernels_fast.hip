@@ -482,8 +482,14 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
 // (r0, r1, r2) line is exchanged through a double-buffered LDS line, the horizontal pass
 // accumulates in double in optflowgf.cpp's order.  Bit-identical to k_polyexp / the oracle.
 // ---------------------------------------------------------------------------------------------
+#ifdef OFARN_PE_WAVES      // experiment: ask the register allocator for this many waves per SIMD (default: 74 VGPRs = 6 waves)
+#define OFARN_PE_OCC __attribute__((amdgpu_waves_per_eu(OFARN_PE_WAVES, OFARN_PE_WAVES)))
+#else
+#define OFARN_PE_OCC
+#define OFARN_PE_WAVES 6
+#endif
 template <int N, int SRC>
-__global__ __launch_bounds__(FI_THREADS) void k_polyexp_march(const void *__restrict__ src, size_t src_stride,
+__global__ __launch_bounds__(FI_THREADS) OFARN_PE_OCC void k_polyexp_march(const void *__restrict__ src, size_t src_stride,
                                                               float *__restrict__ R, int w, int h, int strip_h,
                                                               PolyCoef c, float k0, float k1, float k2, int nt)
 {
@@ -1211,7 +1217,7 @@ static void launch_polyexp_march_n(hipStream_t s, const void *src, size_t src_st
                                    int nframes, const PolyCoef &c, const float *blur3)
 {
     constexpr int OUTW = march_out_width(N);
-    const int strip_h = best_strip_units(h, 1, 2 * N, (int)cdivu(w, OUTW) * nframes, 6);
+    const int strip_h = best_strip_units(h, 1, 2 * N, (int)cdivu(w, OUTW) * nframes, OFARN_PE_WAVES);
     dim3 grid(cdivu(w, OUTW), cdivu(h, strip_h), nframes);
     const int nt = nt_hint((size_t)nframes * w * h * 20);
     if (src_is_u8)
