@@ -37,6 +37,22 @@ for i in range(N):
         # the same pair as a streaming session (round 3): prime with a, then one turn with b -- must equal the pair call
         assert eng.stream_next(a, None if init is None else init.copy()) is None
         got_s = eng.stream_next(b, None if init is None else init.copy())
+    if i % 4 == 1 and not (kw["flags"] & 4):
+        # a small video-order batch through the wave scheduler (3 frames = 2 pairs, one wave or two), danger maps included:
+        # pair 0 must equal the pair call, the maps must equal the reference's NumPy filter on the returned flow
+        c = translated_pair(h, w, 70000 + i, max_shift=4)[0]
+        gs = int(rng.choice([12, 20, 30]))
+        with H.FarnebackEngine(w, h, int(rng.choice([1, 2])), grid_step=gs, **kw) as eng:
+            fl, mk, vv = eng.calc_batch(np.stack([a, b, c]), H.PAIRS_CONSECUTIVE)
+        P = len(H.grid_points(w, h, gs))
+        okb = np.array_equal(fl[0], got)
+        if P >= 2:
+            for j in range(2):
+                m_ref, v_ref = O.danger_map_numpy(fl[j], w, h, gs)
+                okb = okb and np.array_equal(mk[j], m_ref) and np.array_equal(vv[j], v_ref)
+        if not okb:
+            bad += 1
+            print("BATCH MISMATCH", w, h, kw, gs, flush=True)
     if not np.array_equal(got_s, got):
         bad += 1
         print("STREAM MISMATCH", w, h, kw, float(np.abs(got_s - got).max()), flush=True)
