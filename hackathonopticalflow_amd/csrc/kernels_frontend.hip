@@ -5,6 +5,7 @@
 //                  OPTFLOW_USE_INITIAL_FLOW                                 optflowgf.cpp calc()
 //   k_flow_hsv     draw_hsv: direction -> hue, length -> value, HSV2BGR     DenseOF.py:109-124
 //   k_flow_arrows  draw_flow: step-14 sampling and int32 line end points    DenseOF.py:40-49
+//   k_add_u8       cv2.add on uint8 images (layer compositions)            DenseOF.py:574-582
 //   k_draw_lamps   draw_sparse_lamps: a filled disc per danger point,        pathfinder_viewer.py:196-222
 //                  optionally cv2.add-ed onto the frame                      pathfinder_viewer.py:299-300
 //
@@ -193,8 +194,9 @@ __device__ __forceinline__ void hsv2bgr_px(uint8_t H, uint8_t S, uint8_t V, uint
     out[2] = sat_round_u8(r * 255.f);
 }
 
+// base (or nullptr): the BGR image is added onto it with saturation -- cv2.add(output_bgr, draw_hsv(flow)), DenseOF.py:577-578
 __global__ __launch_bounds__(256) void k_flow_hsv(const float2 *__restrict__ flow, size_t npx, uint8_t *__restrict__ hsv,
-                                                  uint8_t *__restrict__ bgr)
+                                                  uint8_t *__restrict__ bgr, const uint8_t *__restrict__ base)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= npx) return;
@@ -207,15 +209,59 @@ __global__ __launch_bounds__(256) void k_flow_hsv(const float2 *__restrict__ flo
     if (bgr) {
         uint8_t o[3];
         hsv2bgr_px(H, 255, V, o);
+        if (base) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const int t = (int)o[k] + (int)base[i * 3 + k]; o[k] = (uint8_t)(t > 255 ? 255 : t); }
+        }
         bgr[i * 3] = o[0]; bgr[i * 3 + 1] = o[1]; bgr[i * 3 + 2] = o[2];
     }
 }
 
-void launch_flow_hsv(hipStream_t s, const float *flow, size_t npx, uint8_t *hsv, uint8_t *bgr)
+void launch_flow_hsv(hipStream_t s, const float *flow, size_t npx, uint8_t *hsv, uint8_t *bgr, const uint8_t *base)
 {
     if (npx == 0) return;
     hipLaunchKernelGGL(k_flow_hsv, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s,
-                       reinterpret_cast<const float2 *>(flow), npx, hsv, bgr);
+                       reinterpret_cast<const float2 *>(flow), npx, hsv, bgr, base);
+}
+
+// cv2.add on uint8 images: saturating byte-wise sum (the layer compositions of DenseOF.py:574-582, pathfinder_viewer.py:297-300).
+// 16 bytes per thread where all three pointers are 16-byte aligned, bytes otherwise.
+__global__ __launch_bounds__(256) void k_add_u8(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, uint8_t *__restrict__ out,
+                                                size_t n, int vec)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (vec) {
+        const size_t p = i * 16;
+        if (p + 16 <= n) {
+            const uint4 x = *reinterpret_cast<const uint4 *>(a + p), y = *reinterpret_cast<const uint4 *>(b + p);
+            const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+            uint32_t r[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t t = ((xs[k] >> (8 * j)) & 255u) + ((ys[k] >> (8 * j)) & 255u);
+                    acc |= (t > 255u ? 255u : t) << (8 * j);
+                }
+                r[k] = acc;
+            }
+            *reinterpret_cast<uint4 *>(out + p) = make_uint4(r[0], r[1], r[2], r[3]);
+        } else {
+            for (size_t q = p; q < n; q++) { const int t = (int)a[q] + (int)b[q]; out[q] = (uint8_t)(t > 255 ? 255 : t); }
+        }
+    } else if (i < n) {
+        const int t = (int)a[i] + (int)b[i];
+        out[i] = (uint8_t)(t > 255 ? 255 : t);
+    }
+}
+
+void launch_add_u8(hipStream_t s, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n)
+{
+    if (n == 0) return;
+    const int vec = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0;
+    const size_t threads = vec ? (n + 15) / 16 : n;
+    hipLaunchKernelGGL(k_add_u8, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a, b, out, n, vec);
 }
 
 __global__ __launch_bounds__(256) void k_hsv2bgr(const uint8_t *__restrict__ hsv, size_t npx, uint8_t *__restrict__ bgr)

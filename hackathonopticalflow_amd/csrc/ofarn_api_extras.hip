@@ -143,6 +143,33 @@ int ofarn_hsv2bgr(ofarn_ctx *c, const uint8_t *h_hsv, size_t npx, uint8_t *h_bgr
     return OFARN_OK;
 }
 
+int ofarn_add_u8_device(ofarn_ctx *c, const uint8_t *d_a, const uint8_t *d_b, size_t n, uint8_t *d_out, void *hip_stream)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    if (n > 0 && (!d_a || !d_b || !d_out)) return fail(OFARN_E_INVALID, "a, b and out must not be NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    launch_add_u8(pick_stream(c, hip_stream), d_a, d_b, d_out, n);
+    HIP_TRY(hipGetLastError());
+    return OFARN_OK;
+}
+
+int ofarn_add_u8(ofarn_ctx *c, const uint8_t *h_a, const uint8_t *h_b, size_t n, uint8_t *h_out)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    if (n == 0) return OFARN_OK;
+    if (!h_a || !h_b || !h_out) return fail(OFARN_E_INVALID, "a, b and out must not be NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    DevTmp a, b;
+    int rc;
+    if ((rc = a.alloc(n)) || (rc = b.alloc(n))) return rc;
+    HIP_TRY(hipMemcpyAsync(a.p, h_a, n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(b.p, h_b, n, hipMemcpyHostToDevice, c->stream));
+    launch_add_u8(c->stream, a.as<uint8_t>(), b.as<uint8_t>(), a.as<uint8_t>(), n);
+    HIP_TRY(hipMemcpyAsync(h_out, a.p, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return OFARN_OK;
+}
+
 int ofarn_draw_lamps_device(ofarn_ctx *c, const uint8_t *d_mask, const uint8_t *d_v, int n, int w, int h, int radius,
                             const uint8_t *d_base, uint8_t *d_out, void *hip_stream)
 {

@@ -342,6 +342,29 @@ int ofarn_stream_view_lamps(ofarn_ctx *c, int w, int h, int radius, int over_fra
     return end_call(c, s);
 }
 
+// draw_hsv of the flow the most recent ofarn_stream_next_view turn left on the device; with over_frame added onto the turn's BGR frame,
+// cv2.add(output_bgr, draw_hsv(flow)) (DenseOF.py:577-578).
+int ofarn_stream_view_rainbow(ofarn_ctx *c, int w, int h, int over_frame, uint8_t *h_out)
+{
+    if (!c || !h_out) return fail(OFARN_E_INVALID, "ctx or out is NULL");
+    ofarn_ctx::Stream &st = c->stream_state;
+    if (!(st.have && st.view_flow_valid && st.w == w && st.h == h) || !c->st_flow)
+        return fail(OFARN_E_INVALID, "no streaming turn of %dx%d has produced a flow on this context yet", w, h);
+    if (over_frame && !st.view_bgr_valid)
+        return fail(OFARN_E_INVALID, "over_frame needs the turn's frame in BGR, and the most recent view turn was given a gray frame");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t img = (size_t)w * h * 3;
+    int rc = grow_u8(c, &st.d_lamps, &st.lamps_cap, img, "rainbow layer");
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    if ((rc = begin_call(c, s))) return rc;
+    launch_flow_hsv(s, c->st_flow, (size_t)w * h, nullptr, st.d_lamps, over_frame ? st.d_bgr : nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_out, st.d_lamps, img, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return end_call(c, s);
+}
+
 // Pipelined submission: enqueue the turn and return; the flow lands in h_flow asynchronously (copy stream), while the caller
 // already submits the next frame -- whose kernels then run beside this turn's device-to-host transfer (16.6 MB at 1080p, about as
 // long as the kernels themselves).

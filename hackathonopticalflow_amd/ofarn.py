@@ -127,6 +127,9 @@ ABI = {
                                          C.c_void_p, C.c_void_p]),
     "ofarn_stream_view_flow": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ofarn_stream_view_lamps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ofarn_stream_view_rainbow": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ofarn_add_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ofarn_add_u8_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ofarn_draw_lamps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ofarn_draw_lamps_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                           C.c_void_p, C.c_void_p]),
@@ -553,6 +556,14 @@ class FarnebackEngine:
         _check(self._lib.ofarn_stream_view_lamps(self._h, width, height, int(radius), 1 if over_frame else 0, C.c_void_p(o.ctypes.data)))
         return o
 
+    def stream_view_rainbow(self, width, height, over_frame=False, out=None):
+        """draw_hsv of the flow the most recent stream_next_view turn left on the device, BGR uint8[H,W,3]; over_frame: added onto
+        the turn's BGR frame as DenseOF.py:577-578 does."""
+        o = out if (isinstance(out, np.ndarray) and out.dtype == np.uint8 and out.shape == (height, width, 3)
+                    and out.flags.c_contiguous) else np.empty((height, width, 3), np.uint8)
+        _check(self._lib.ofarn_stream_view_rainbow(self._h, width, height, 1 if over_frame else 0, C.c_void_p(o.ctypes.data)))
+        return o
+
     def stream_next_device(self, d_frame, width, height, d_flow=None, d_mask=None, d_v=None, stream=None, bgr=False) -> bool:
         """Device-resident turn (torch CUDA tensors or raw addresses), enqueued on `stream`, not synchronised.  Returns True when
         a flow / danger map was enqueued, False for the priming call."""
@@ -757,6 +768,19 @@ class FarnebackEngine:
         _check(self._lib.ofarn_flow_arrows(self._h, f.ctypes.data_as(_fp), n, w, h, int(step),
                                            lines.ctypes.data_as(C.POINTER(C.c_int32))))
         return lines[0] if single else lines
+
+    def add_u8(self, a, b):
+        """cv2.add(a, b) for uint8 arrays of one shape: saturating sum (the viewers' layer stacking, DenseOF.py:574-582)."""
+        x, y = np.ascontiguousarray(a, np.uint8), np.ascontiguousarray(b, np.uint8)
+        if x.shape != y.shape:
+            raise ValueError(f"a and b must have the same shape, got {x.shape} and {y.shape}")
+        out = np.empty_like(x)
+        _check(self._lib.ofarn_add_u8(self._h, C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data), x.size, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def add_u8_device(self, d_a, d_b, n, d_out, stream=None):
+        _check(self._lib.ofarn_add_u8_device(self._h, _ptr(d_a, "d_a", "uint8", n), _ptr(d_b, "d_b", "uint8", n), n,
+                                             _ptr(d_out, "d_out", "uint8", n), _stream_arg(stream)))
 
     def draw_lamps(self, mask, v, shape, radius=6, base=None):
         """draw_sparse_lamps (pathfinder_viewer.py:196-222) for danger maps on this engine's grid: mask, v uint8[P] (or [n,P]) as
@@ -1074,10 +1098,23 @@ class FlowStream:
         h, w = self._shape
         return self._eng.stream_view_flow(w, h)
 
+    def view_rainbow(self, over_frame=False):
+        """draw_hsv of the last next_view turn's flow, BGR uint8[H,W,3]; over_frame=True: cv2.add-ed onto the turn's BGR frame
+        (DenseOF.py:577-578).  The array is reused by the next call."""
+        h, w = self._view_size()
+        if "rainbow_after" not in self._view:
+            self._view["rainbow_after"] = pinned_empty((h, w, 3), np.uint8)
+        return self._eng.stream_view_rainbow(w, h, over_frame, out=self._view["rainbow_after"])
+
+    def _view_size(self):
+        if getattr(self, "_view", None) is None or self._eng is None:
+            raise ValueError("no next_view turn has run on this stream yet")
+        return self._view_shape
+
     def view_lamps(self, radius=6, over_frame=False):
         """The viewer's obstacle layer of the last next_view(danger=True) turn (draw_sparse_lamps, pathfinder_viewer.py:196-222),
         BGR uint8[H,W,3]; over_frame=True: cv2.add-ed onto the turn's BGR frame (:299-300).  The array is reused by the next call."""
-        h, w = self._shape
+        h, w = self._view_size()
         if "lamps" not in self._view:
             self._view["lamps"] = pinned_empty((h, w, 3), np.uint8)
         return self._eng.stream_view_lamps(w, h, radius, over_frame, out=self._view["lamps"])

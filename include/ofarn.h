@@ -146,6 +146,9 @@ int ofarn_stream_view_flow(ofarn_ctx *ctx, int w, int h, float *h_flow);
  * cv2.add(output_bgr, draw_sparse_lamps(...)), pathfinder_viewer.py:299-300 -- which the turn had uploaded anyway (needs bgr != 0
  * and h_mask / h_v in that ofarn_stream_next_view call). */
 int ofarn_stream_view_lamps(ofarn_ctx *ctx, int w, int h, int radius, int over_frame, uint8_t *h_out);
+/* draw_hsv of that turn's flow (which stayed on the device), BGR uint8[h][w][3]; over_frame != 0: added onto the turn's BGR frame,
+ * output_bgr = cv2.add(output_bgr, draw_hsv(flow)) (DenseOF.py:577-578). */
+int ofarn_stream_view_rainbow(ofarn_ctx *ctx, int w, int h, int over_frame, uint8_t *h_out);
 /* Pipelined form for throughput: ofarn_stream_submit enqueues the turn (upload, kernels, transfer of the flow into h_flow on a copy
  * stream) and returns without waiting; the caller submits the next frame at once, whose kernels then run BESIDE this turn's
  * device-to-host transfer (at 1080p the 16.6 MB of flow take about as long over PCIe as the kernels).  h_flow of a turn is complete
@@ -195,6 +198,11 @@ int ofarn_flow_arrow_count(int w, int h, int step, int *nx, int *ny);
 int ofarn_flow_arrows(ofarn_ctx *ctx, const float *h_flow, int n, int w, int h, int step, int32_t *h_lines);
 int ofarn_flow_arrows_device(ofarn_ctx *ctx, const float *d_flow, int n, int w, int h, int step,
                              int32_t *d_lines, void *hip_stream);
+
+/* cv2.add on uint8 images, n bytes: out = saturate(a + b) -- how the viewers stack their layers onto the frame
+ * (DenseOF.py:574-582, pathfinder_viewer.py:297-300).  out may be a or b. */
+int ofarn_add_u8(ofarn_ctx *ctx, const uint8_t *h_a, const uint8_t *h_b, size_t n, uint8_t *h_out);
+int ofarn_add_u8_device(ofarn_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, size_t n, uint8_t *d_out, void *hip_stream);
 
 /* draw_sparse_lamps (pathfinder_viewer.py:196-222) for danger maps on the context's measurement grid: a BGR layer uint8[n][h][w][3]
  * that is black except for one filled disc per danger point (mask != 0) -- hsv[y, x] = (0, 255, V), cv2.cvtColor(HSV2BGR) = (0, 0, V),

@@ -655,6 +655,25 @@ def test_draw_sparse_lamps_bit_exact(H, oracle, h, w, step, radius):
         np.testing.assert_array_equal(d_out[1:].cpu().numpy().reshape(h, w, 3), ref)
 
 
+@pytest.mark.parametrize("shape", [(1080, 1920, 3), (37, 53, 3), (5,), (0,), (64, 64)])
+def test_add_u8_is_cv2_add(H, oracle, shape):
+    """cv2.add on uint8 (how the viewers stack layers onto the frame, DenseOF.py:574-582): saturating, any size and alignment."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(int(np.prod(shape)) + 1)
+    a, b = rng.integers(0, 256, shape, dtype=np.uint8), rng.integers(0, 256, shape, dtype=np.uint8)
+    with H.FarnebackEngine(8, 8, 1) as eng:
+        np.testing.assert_array_equal(eng.add_u8(a, b), oracle.cv_add_u8(a, b))
+        if a.size > 3:
+            d_a, d_b = torch.from_numpy(a.reshape(-1)).cuda(), torch.from_numpy(b.reshape(-1)).cuda()
+            out = torch.zeros(a.size, dtype=torch.uint8, device="cuda")
+            eng.add_u8_device(d_a[3:], d_b[3:], a.size - 3, out[3:])          # unaligned: byte path
+            eng.add_u8_device(d_a, d_b, a.size, d_a)                         # aligned, in place
+            torch.cuda.synchronize()
+            ref = oracle.cv_add_u8(a, b).reshape(-1)
+            np.testing.assert_array_equal(out[3:].cpu().numpy(), ref[3:])
+            np.testing.assert_array_equal(d_a.cpu().numpy(), ref)
+
+
 def test_draw_sparse_lamps_errors(H):
     with H.FarnebackEngine(64, 48, 1, grid_step=12) as eng:
         P = len(H.grid_points(64, 48, 12))

@@ -368,6 +368,8 @@ def test_view_turn_returns_what_the_viewer_draws(H, oracle):
     fr = video(5, h, w, 51)
     bgr = np.stack([np.stack([g, g, g], -1) for g in fr])
     with H.FlowStream(levels=3) as st, H.FarnebackEngine(w, h, 1, levels=3) as eng:
+        with pytest.raises(ValueError):
+            st.view_lamps()                                        # nothing has run yet
         assert st.next_view(fr[0]) is None
         for i in range(1, 5):
             frame = bgr[i] if i % 2 == 0 else fr[i]            # gray and BGR frames alternate (gray as BGR converts back to itself)
@@ -380,6 +382,10 @@ def test_view_turn_returns_what_the_viewer_draws(H, oracle):
             np.testing.assert_array_equal(res["v"], v)
             np.testing.assert_array_equal(res["lines"], eng.flow_arrows(flow, 14))
             np.testing.assert_array_equal(res["rainbow"], eng.flow_hsv(flow))
+            # the rainbow again, after the fact, alone and added onto the turn's own frame (DenseOF.py:577-578)
+            np.testing.assert_array_equal(st.view_rainbow(), res["rainbow"])
+            if i % 2 == 0:
+                np.testing.assert_array_equal(st.view_rainbow(over_frame=True), oracle.cv_add_u8(bgr[i], res["rainbow"]))
             # the obstacle layer of the same turn, alone and added onto the turn's own frame (pathfinder_viewer.py:299-300)
             layer = eng.draw_lamps(mask, v, (h, w))
             np.testing.assert_array_equal(st.view_lamps(), layer)
@@ -397,6 +403,8 @@ def test_view_turn_returns_what_the_viewer_draws(H, oracle):
             st.view_flow()
         with pytest.raises(ValueError):
             st.view_lamps()
+        with pytest.raises(ValueError):
+            st.view_rainbow()
     with H.FarnebackEngine(w, h, 1, levels=3, flags=4) as eng:
         with pytest.raises(NotImplementedError):
             eng.stream_next_view(fr[0])
