@@ -7,9 +7,9 @@ cv2.calcOpticalFlowFarneback; pathfinder_viewer.py:159-176 vector filter), plus 
 from .ofarn import (FILTER_DENSEOF, FILTER_VIEWER, FlowStream, MultiGpuEngine, shard_pairs_c, pinned_empty, OPTFLOW_FARNEBACK_GAUSSIAN, OPTFLOW_USE_INITIAL_FLOW,  # noqa: F401
                     FarnebackEngine, OfarnLkParams, OfarnParams, PAIRS_CONSECUTIVE, PAIRS_INDEPENDENT,
                     calcOpticalFlowFarneback, calcOpticalFlowPyrLK, get_flow_lk, make_lk_params, calculate_optical_flow, close_cached_engines, cvtColor_bgr2gray,
-                    danger_map, draw_hsv, draw_sparse_lamps, flow_lines, grid_points, level_plan, load_library, make_params)
+                    danger_map, draw_flow, draw_hsv, draw_sparse_lamps, flow_lines, grid_points, level_plan, load_library, make_params)
 
 __all__ = ["FILTER_DENSEOF", "FILTER_VIEWER", "FlowStream", "MultiGpuEngine", "shard_pairs_c", "pinned_empty", "OPTFLOW_FARNEBACK_GAUSSIAN", "OPTFLOW_USE_INITIAL_FLOW",
            "FarnebackEngine", "OfarnLkParams", "OfarnParams", "PAIRS_CONSECUTIVE", "PAIRS_INDEPENDENT",
            "calcOpticalFlowFarneback", "calcOpticalFlowPyrLK", "get_flow_lk", "make_lk_params", "calculate_optical_flow", "close_cached_engines", "cvtColor_bgr2gray",
-           "danger_map", "draw_hsv", "draw_sparse_lamps", "flow_lines", "grid_points", "level_plan", "load_library", "make_params"]
+           "danger_map", "draw_flow", "draw_hsv", "draw_sparse_lamps", "flow_lines", "grid_points", "level_plan", "load_library", "make_params"]

@@ -5,6 +5,7 @@
 //                  OPTFLOW_USE_INITIAL_FLOW                                 optflowgf.cpp calc()
 //   k_flow_hsv     draw_hsv: direction -> hue, length -> value, HSV2BGR     DenseOF.py:109-124
 //   k_flow_arrows  draw_flow: step-14 sampling and int32 line end points    DenseOF.py:40-49
+//   k_draw_flow    draw_flow as an image: cv2.polylines + cv2.circle raster  DenseOF.py:40-59
 //   k_add_u8       cv2.add on uint8 images (layer compositions)            DenseOF.py:574-582
 //   k_draw_lamps   draw_sparse_lamps: a filled disc per danger point,        pathfinder_viewer.py:196-222
 //                  optionally cv2.add-ed onto the frame                      pathfinder_viewer.py:299-300
@@ -307,6 +308,108 @@ void launch_flow_arrows(hipStream_t s, const float *flow, int w, int h, int npai
     if (n == 0) return;
     hipLaunchKernelGGL(k_flow_arrows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const float2 *>(flow), w, h, npairs, nx, ny, start, step, lines);
+}
+
+// ---------------------------------------------------------------------------------------------
+// draw_flow as an image (DenseOF.py:40-59, pathfinder_viewer.py:51-73): cv2.polylines(img, lines, False, (0, 255, 0)) with the
+// default thickness 1 / LINE_8 -- drawing.cpp PolyLine -> ThickLine -> Line: clipLine() to the image, then LineIterator (8-connected
+// Bresenham, leftToRight) -- and cv2.circle(img, (x1, y1), 1, (0, 255, 0), -1) at every start point.  Everything drawn has one
+// colour, so the image is the union of the pixels whatever the drawing order: one thread per arrow sets the G byte of its pixels
+// to 255 in an image the host has initialised (zeros: the layer; a copy of the frame: cv2.add(frame, layer), whose B and R do not
+// change and whose G saturates to 255).
+__device__ __forceinline__ bool cv_clip_line(long long right, long long bottom, long long &x1, long long &y1, long long &x2, long long &y2)
+{
+    int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+    int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+        long long a;
+        if (c1 & 12) {
+            a = c1 < 8 ? 0 : bottom;
+            x1 += (long long)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
+            y1 = a;
+            c1 = (x1 < 0) + (x1 > right) * 2;
+        }
+        if (c2 & 12) {
+            a = c2 < 8 ? 0 : bottom;
+            x2 += (long long)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
+            y2 = a;
+            c2 = (x2 < 0) + (x2 > right) * 2;
+        }
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            if (c1) {
+                a = c1 == 1 ? 0 : right;
+                y1 += (long long)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
+                x1 = a;
+                c1 = 0;
+            }
+            if (c2) {
+                a = c2 == 1 ? 0 : right;
+                y2 += (long long)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
+                x2 = a;
+                c2 = 0;
+            }
+        }
+    }
+    return (c1 | c2) == 0;
+}
+
+__global__ __launch_bounds__(256) void k_draw_flow(const float2 *__restrict__ flow, int w, int h, int npairs, int nx, int ny,
+                                                   double start, double step, uint8_t *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t per = (size_t)nx * ny;
+    if (i >= per * npairs) return;
+    const int p = (int)(i / per), r = (int)(i % per);
+    const int iy = r / nx, ix = r % nx;
+    const int gx = (int)(start + ix * step), gy = (int)(start + iy * step);
+    const float2 f = flow[(size_t)p * w * h + (size_t)gy * w + gx];
+    // the int32 `lines` entry of this arrow (k_flow_arrows)
+    const int ax = (int32_t)((double)gx + 0.5), ay = (int32_t)((double)gy + 0.5);
+    const int bx = (int32_t)(((double)gx - (double)f.x) + 0.5), by = (int32_t)(((double)gy - (double)f.y) + 0.5);
+    uint8_t *img = out + (size_t)p * w * h * 3;
+    // Line(): clip if an end point lies outside, then LineIterator(pt1, pt2, 8, leftToRight = true)
+    long long x1 = ax, y1 = ay, x2 = bx, y2 = by;
+    bool draw = true;
+    if ((unsigned long long)x1 >= (unsigned long long)w || (unsigned long long)x2 >= (unsigned long long)w ||
+        (unsigned long long)y1 >= (unsigned long long)h || (unsigned long long)y2 >= (unsigned long long)h)
+        draw = cv_clip_line(w - 1, h - 1, x1, y1, x2, y2);
+    if (draw) {
+        int px = (int)x1, py = (int)y1;
+        int dx = (int)(x2 - x1), dy = (int)(y2 - y1);
+        int delta_x = 1, delta_y = 1;
+        if (dx < 0) { dx = -dx; dy = -dy; px = (int)x2; py = (int)y2; }          // leftToRight: start from the other end
+        if (dy < 0) { dy = -dy; delta_y = -1; }
+        const bool vert = dy > dx;
+        if (vert) { const int t = dx; dx = dy; dy = t; }
+        // 8-connected: the major axis advances every step, the minor one when err < 0
+        int err = dx - (dy + dy);
+        const int plus_delta = dx + dx, minus_delta = -(dy + dy);
+        const int major_x = vert ? 0 : delta_x, major_y = vert ? delta_y : 0;
+        const int minor_x = vert ? delta_x : 0, minor_y = vert ? 0 : delta_y;
+        const int count = dx + 1;
+        for (int k = 0; k < count; k++) {
+            if ((unsigned)px < (unsigned)w && (unsigned)py < (unsigned)h) img[((size_t)py * w + px) * 3 + 1] = 255;
+            const int mask = err < 0 ? -1 : 0;
+            err += minus_delta + (plus_delta & mask);
+            px += major_x + (minor_x & mask);
+            py += major_y + (minor_y & mask);
+        }
+    }
+    // cv2.circle(img, (x1, y1), 1, colour, -1): the filled radius-1 raster is the centre and its four neighbours
+    const int cx[5] = {0, -1, 1, 0, 0}, cy[5] = {0, 0, 0, -1, 1};
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int qx = ax + cx[k], qy = ay + cy[k];
+        if ((unsigned)qx < (unsigned)w && (unsigned)qy < (unsigned)h) img[((size_t)qy * w + qx) * 3 + 1] = 255;
+    }
+}
+
+void launch_draw_flow(hipStream_t s, const float *flow, int w, int h, int npairs, int nx, int ny, double start, double step, uint8_t *out)
+{
+    const size_t n = (size_t)nx * ny * npairs;
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_draw_flow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float2 *>(flow), w, h,
+                       npairs, nx, ny, start, step, out);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -143,6 +143,49 @@ int ofarn_hsv2bgr(ofarn_ctx *c, const uint8_t *h_hsv, size_t npx, uint8_t *h_bgr
     return OFARN_OK;
 }
 
+int ofarn_draw_flow_device(ofarn_ctx *c, const float *d_flow, int n, int w, int h, int step, const uint8_t *d_base, uint8_t *d_out,
+                           void *hip_stream)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    if (!d_flow || !d_out) return fail(OFARN_E_INVALID, "flow and out must not be NULL");
+    if (n < 0 || w < 1 || h < 1 || step < 1) return fail(OFARN_E_INVALID, "bad arguments n=%d %dx%d step=%d", n, w, h, step);
+    if (n == 0) return OFARN_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    double st;
+    const int nx = arrow_axis(w, step, &st), ny = arrow_axis(h, step, &st);
+    const size_t bytes = (size_t)n * w * h * 3;
+    hipStream_t s = pick_stream(c, hip_stream);
+    if (!d_base) HIP_TRY(hipMemsetAsync(d_out, 0, bytes, s));
+    else if (d_base != d_out) HIP_TRY(hipMemcpyAsync(d_out, d_base, bytes, hipMemcpyDeviceToDevice, s));
+    launch_draw_flow(s, d_flow, w, h, n, nx, ny, st, (double)step, d_out);
+    HIP_TRY(hipGetLastError());
+    return OFARN_OK;
+}
+
+int ofarn_draw_flow(ofarn_ctx *c, const float *h_flow, int n, int w, int h, int step, const uint8_t *h_base, uint8_t *h_out)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    if (!h_flow || !h_out) return fail(OFARN_E_INVALID, "flow and out must not be NULL");
+    if (n < 0 || w < 1 || h < 1 || step < 1) return fail(OFARN_E_INVALID, "bad arguments n=%d %dx%d step=%d", n, w, h, step);
+    if (n == 0) return OFARN_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    double st;
+    const int nx = arrow_axis(w, step, &st), ny = arrow_axis(h, step, &st);
+    const size_t npx = (size_t)w * h, img = npx * 3;
+    DevTmp in, out;
+    int rc;
+    if ((rc = in.alloc(npx * 8)) || (rc = out.alloc(img))) return rc;
+    for (int i = 0; i < n; i++) {
+        HIP_TRY(hipMemcpyAsync(in.p, h_flow + (size_t)i * npx * 2, npx * 8, hipMemcpyHostToDevice, c->stream));
+        if (h_base) HIP_TRY(hipMemcpyAsync(out.p, h_base + (size_t)i * img, img, hipMemcpyHostToDevice, c->stream));
+        else HIP_TRY(hipMemsetAsync(out.p, 0, img, c->stream));
+        launch_draw_flow(c->stream, in.as<float>(), w, h, 1, nx, ny, st, (double)step, out.as<uint8_t>());
+        HIP_TRY(hipMemcpyAsync(h_out + (size_t)i * img, out.p, img, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return OFARN_OK;
+}
+
 int ofarn_add_u8_device(ofarn_ctx *c, const uint8_t *d_a, const uint8_t *d_b, size_t n, uint8_t *d_out, void *hip_stream)
 {
     if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");

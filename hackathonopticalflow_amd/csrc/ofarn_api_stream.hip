@@ -342,6 +342,34 @@ int ofarn_stream_view_lamps(ofarn_ctx *c, int w, int h, int radius, int over_fra
     return end_call(c, s);
 }
 
+// draw_flow as an image for the flow the most recent ofarn_stream_next_view turn left on the device: the arrows rasterised as
+// cv2.polylines / cv2.circle draw them (DenseOF.py:40-59); with over_frame onto the turn's BGR frame (cv2.add, DenseOF.py:574).
+int ofarn_stream_view_arrows(ofarn_ctx *c, int w, int h, int step, int over_frame, uint8_t *h_out)
+{
+    if (!c || !h_out) return fail(OFARN_E_INVALID, "ctx or out is NULL");
+    if (step < 1) return fail(OFARN_E_INVALID, "arrow step must be >= 1, got %d", step);
+    ofarn_ctx::Stream &st = c->stream_state;
+    if (!(st.have && st.view_flow_valid && st.w == w && st.h == h) || !c->st_flow)
+        return fail(OFARN_E_INVALID, "no streaming turn of %dx%d has produced a flow on this context yet", w, h);
+    if (over_frame && !st.view_bgr_valid)
+        return fail(OFARN_E_INVALID, "over_frame needs the turn's frame in BGR, and the most recent view turn was given a gray frame");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t img = (size_t)w * h * 3;
+    int rc = grow_u8(c, &st.d_lamps, &st.lamps_cap, img, "arrow layer");
+    if (rc) return rc;
+    double astart = 0;
+    const int nx = arrow_axis(w, step, &astart), ny = arrow_axis(h, step, &astart);
+    hipStream_t s = c->stream;
+    if ((rc = begin_call(c, s))) return rc;
+    if (over_frame) HIP_TRY(hipMemcpyAsync(st.d_lamps, st.d_bgr, img, hipMemcpyDeviceToDevice, s));
+    else HIP_TRY(hipMemsetAsync(st.d_lamps, 0, img, s));
+    launch_draw_flow(s, c->st_flow, w, h, 1, nx, ny, astart, (double)step, st.d_lamps);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_out, st.d_lamps, img, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return end_call(c, s);
+}
+
 // draw_hsv of the flow the most recent ofarn_stream_next_view turn left on the device; with over_frame added onto the turn's BGR frame,
 // cv2.add(output_bgr, draw_hsv(flow)) (DenseOF.py:577-578).
 int ofarn_stream_view_rainbow(ofarn_ctx *c, int w, int h, int over_frame, uint8_t *h_out)

@@ -127,6 +127,9 @@ ABI = {
                                          C.c_void_p, C.c_void_p]),
     "ofarn_stream_view_flow": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ofarn_stream_view_lamps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ofarn_stream_view_arrows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ofarn_draw_flow": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ofarn_draw_flow_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ofarn_stream_view_rainbow": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ofarn_add_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ofarn_add_u8_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
@@ -556,6 +559,14 @@ class FarnebackEngine:
         _check(self._lib.ofarn_stream_view_lamps(self._h, width, height, int(radius), 1 if over_frame else 0, C.c_void_p(o.ctypes.data)))
         return o
 
+    def stream_view_arrows(self, width, height, step=14, over_frame=False, out=None):
+        """draw_flow's image for the flow the most recent stream_next_view turn left on the device (DenseOF.py:40-59), BGR
+        uint8[H,W,3]; over_frame: the turn's BGR frame with the layer added (DenseOF.py:574)."""
+        o = out if (isinstance(out, np.ndarray) and out.dtype == np.uint8 and out.shape == (height, width, 3)
+                    and out.flags.c_contiguous) else np.empty((height, width, 3), np.uint8)
+        _check(self._lib.ofarn_stream_view_arrows(self._h, width, height, int(step), 1 if over_frame else 0, C.c_void_p(o.ctypes.data)))
+        return o
+
     def stream_view_rainbow(self, width, height, over_frame=False, out=None):
         """draw_hsv of the flow the most recent stream_next_view turn left on the device, BGR uint8[H,W,3]; over_frame: added onto
         the turn's BGR frame as DenseOF.py:577-578 does."""
@@ -768,6 +779,31 @@ class FarnebackEngine:
         _check(self._lib.ofarn_flow_arrows(self._h, f.ctypes.data_as(_fp), n, w, h, int(step),
                                            lines.ctypes.data_as(C.POINTER(C.c_int32))))
         return lines[0] if single else lines
+
+    def draw_flow(self, flow, step=14, base=None):
+        """draw_flow (DenseOF.py:40-59) as the reference returns it: BGR uint8[H,W,3] (or a stack) with the arrows rasterised the way
+        cv2.polylines and cv2.circle draw them; base: cv2.add(base, layer) instead."""
+        f = np.ascontiguousarray(flow, np.float32)
+        single = f.ndim == 3
+        f = f[None] if single else f
+        n, h, w, two = f.shape
+        if two != 2:
+            raise ValueError("flow must be float32[..., H, W, 2]")
+        b = None
+        if base is not None:
+            b = np.ascontiguousarray(base, np.uint8)
+            if b.size != n * h * w * 3:
+                raise ValueError(f"base must be uint8[{'' if single else 'n,'}{h},{w},3]")
+        out = np.empty((n, h, w, 3), np.uint8)
+        _check(self._lib.ofarn_draw_flow(self._h, C.c_void_p(f.ctypes.data), n, w, h, int(step),
+                                         C.c_void_p(b.ctypes.data) if b is not None else None, C.c_void_p(out.ctypes.data)))
+        return out[0] if single else out
+
+    def draw_flow_device(self, d_flow, n, width, height, d_out, step=14, d_base=None, stream=None):
+        npx = n * width * height
+        _check(self._lib.ofarn_draw_flow_device(self._h, _ptr(d_flow, "d_flow", "float32", npx * 2), n, width, height, int(step),
+                                                _ptr(d_base, "d_base", "uint8", npx * 3), _ptr(d_out, "d_out", "uint8", npx * 3),
+                                                _stream_arg(stream)))
 
     def add_u8(self, a, b):
         """cv2.add(a, b) for uint8 arrays of one shape: saturating sum (the viewers' layer stacking, DenseOF.py:574-582)."""
@@ -1097,6 +1133,14 @@ class FlowStream:
     def view_flow(self):
         h, w = self._shape
         return self._eng.stream_view_flow(w, h)
+
+    def view_arrows(self, step=14, over_frame=False):
+        """draw_flow's image of the last next_view turn (DenseOF.py:40-59), BGR uint8[H,W,3]; over_frame=True: the turn's BGR frame
+        with the arrows on it (DenseOF.py:574).  The array is reused by the next call."""
+        h, w = self._view_size()
+        if "arrows" not in self._view:
+            self._view["arrows"] = pinned_empty((h, w, 3), np.uint8)
+        return self._eng.stream_view_arrows(w, h, step, over_frame, out=self._view["arrows"])
 
     def view_rainbow(self, over_frame=False):
         """draw_hsv of the last next_view turn's flow, BGR uint8[H,W,3]; over_frame=True: cv2.add-ed onto the turn's BGR frame
@@ -1428,6 +1472,17 @@ def draw_hsv(flow_, device=0):
     f = np.asarray(flow_)
     with _engine_for(f.shape[0], f.shape[1], device) as eng:
         return eng.flow_hsv(f)
+
+
+def draw_flow(img_shape, flow, step=14, device=0):
+    """Drop-in for DenseOF.py:40-59 / pathfinder_viewer.py:51-73 ``draw_flow``: the BGR layer with the motion vectors of every
+    step-th pixel drawn as cv2.polylines and cv2.circle draw them."""
+    f = np.asarray(flow)
+    h, w = int(img_shape[0]), int(img_shape[1])
+    if f.shape[:2] != (h, w):
+        raise ValueError(f"flow {f.shape} does not match img_shape {(h, w)}")
+    with _engine_for(h, w, device) as eng:
+        return eng.draw_flow(f, step)
 
 
 def flow_lines(flow, step=14, device=0):

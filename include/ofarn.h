@@ -149,6 +149,9 @@ int ofarn_stream_view_lamps(ofarn_ctx *ctx, int w, int h, int radius, int over_f
 /* draw_hsv of that turn's flow (which stayed on the device), BGR uint8[h][w][3]; over_frame != 0: added onto the turn's BGR frame,
  * output_bgr = cv2.add(output_bgr, draw_hsv(flow)) (DenseOF.py:577-578). */
 int ofarn_stream_view_rainbow(ofarn_ctx *ctx, int w, int h, int over_frame, uint8_t *h_out);
+/* draw_flow's image for that turn's flow (ofarn_draw_flow below): the arrow layer, or with over_frame != 0 the turn's BGR frame with
+ * the layer added -- output_bgr = cv2.add(output_bgr, draw_flow(shape, flow)) (DenseOF.py:574). */
+int ofarn_stream_view_arrows(ofarn_ctx *ctx, int w, int h, int step, int over_frame, uint8_t *h_out);
 /* Pipelined form for throughput: ofarn_stream_submit enqueues the turn (upload, kernels, transfer of the flow into h_flow on a copy
  * stream) and returns without waiting; the caller submits the next frame at once, whose kernels then run BESIDE this turn's
  * device-to-host transfer (at 1080p the 16.6 MB of flow take about as long over PCIe as the kernels).  h_flow of a turn is complete
@@ -198,6 +201,14 @@ int ofarn_flow_arrow_count(int w, int h, int step, int *nx, int *ny);
 int ofarn_flow_arrows(ofarn_ctx *ctx, const float *h_flow, int n, int w, int h, int step, int32_t *h_lines);
 int ofarn_flow_arrows_device(ofarn_ctx *ctx, const float *d_flow, int n, int w, int h, int step,
                              int32_t *d_lines, void *hip_stream);
+
+/* draw_flow as the reference returns it (DenseOF.py:40-59, pathfinder_viewer.py:51-73): the BGR layer uint8[n][h][w][3] with the
+ * lines of ofarn_flow_arrows drawn by cv2.polylines(img, lines, False, (0, 255, 0)) -- thickness 1, LINE_8: drawing.cpp clipLine +
+ * LineIterator -- and cv2.circle(img, (x1, y1), 1, (0, 255, 0), -1) at every start point.  base (uint8[n][h][w][3] or NULL):
+ * cv2.add(base, layer) instead of the layer (DenseOF.py:574); d_base may equal d_out. */
+int ofarn_draw_flow(ofarn_ctx *ctx, const float *h_flow, int n, int w, int h, int step, const uint8_t *h_base, uint8_t *h_out);
+int ofarn_draw_flow_device(ofarn_ctx *ctx, const float *d_flow, int n, int w, int h, int step, const uint8_t *d_base, uint8_t *d_out,
+                           void *hip_stream);
 
 /* cv2.add on uint8 images, n bytes: out = saturate(a + b) -- how the viewers stack their layers onto the frame
  * (DenseOF.py:574-582, pathfinder_viewer.py:297-300).  out may be a or b. */

@@ -497,6 +497,104 @@ def cv_circle_filled(img, center, radius, color):
         minus -= mask & 2
 
 
+def cv_clip_line(width, height, pt1, pt2):
+    """cv::clipLine(Size2l, Point2l&, Point2l&) (drawing.cpp): -> (visible, pt1, pt2).  64-bit integers, the intersection through a
+    double division truncated toward zero."""
+    x1, y1, x2, y2 = int(pt1[0]), int(pt1[1]), int(pt2[0]), int(pt2[1])
+    right, bottom = width - 1, height - 1
+    if width <= 0 or height <= 0:
+        return False, (x1, y1), (x2, y2)
+    c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8
+    c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8
+    if (c1 & c2) == 0 and (c1 | c2) != 0:
+        if c1 & 12:
+            a = 0 if c1 < 8 else bottom
+            x1 += int(float(a - y1) * float(x2 - x1) / float(y2 - y1))
+            y1 = a
+            c1 = (x1 < 0) + (x1 > right) * 2
+        if c2 & 12:
+            a = 0 if c2 < 8 else bottom
+            x2 += int(float(a - y2) * float(x2 - x1) / float(y2 - y1))
+            y2 = a
+            c2 = (x2 < 0) + (x2 > right) * 2
+        if (c1 & c2) == 0 and (c1 | c2) != 0:
+            if c1:
+                a = 0 if c1 == 1 else right
+                y1 += int(float(a - x1) * float(y2 - y1) / float(x2 - x1))
+                x1 = a
+                c1 = 0
+            if c2:
+                a = 0 if c2 == 1 else right
+                y2 += int(float(a - x2) * float(y2 - y1) / float(x2 - x1))
+                x2 = a
+                c2 = 0
+    return (c1 | c2) == 0, (x1, y1), (x2, y2)
+
+
+def cv_line8(img, pt1, pt2, color):
+    """cv2.line / one segment of cv2.polylines with thickness 1, LINE_8, shift 0: drawing.cpp Line() = clipLine when an end point lies
+    outside the image, then LineIterator(pt1, pt2, connectivity 8, leftToRight=true) -- Bresenham whose major axis advances every
+    step and whose minor axis advances when the error term is negative.  In place."""
+    h, w = img.shape[:2]
+    x1, y1, x2, y2 = int(pt1[0]), int(pt1[1]), int(pt2[0]), int(pt2[1])
+    if not (0 <= x1 < w and 0 <= x2 < w and 0 <= y1 < h and 0 <= y2 < h):
+        ok, (x1, y1), (x2, y2) = cv_clip_line(w, h, (x1, y1), (x2, y2))
+        if not ok:
+            return
+    dx, dy = x2 - x1, y2 - y1
+    delta_x = delta_y = 1
+    px, py = x1, y1
+    if dx < 0:                       # leftToRight
+        dx, dy = -dx, -dy
+        px, py = x2, y2
+    if dy < 0:
+        dy, delta_y = -dy, -1
+    vert = dy > dx
+    if vert:
+        dx, dy = dy, dx
+    err = dx - (dy + dy)
+    plus_delta, minus_delta = dx + dx, -(dy + dy)
+    major = (0, delta_y) if vert else (delta_x, 0)
+    minor = (delta_x, 0) if vert else (0, delta_y)
+    for _ in range(dx + 1):
+        img[py, px] = color
+        neg = err < 0
+        err += minus_delta + (plus_delta if neg else 0)
+        px += major[0] + (minor[0] if neg else 0)
+        py += major[1] + (minor[1] if neg else 0)
+
+
+def cv_polylines(img, pts, is_closed, color):
+    """cv2.polylines(img, pts, isClosed, color) with the default thickness 1 / LINE_8 (drawing.cpp PolyLine)."""
+    for poly in pts:
+        poly = np.asarray(poly).reshape(-1, 2)
+        if len(poly) == 0:
+            continue
+        p0 = poly[-1] if is_closed else poly[0]
+        for p in poly[(0 if is_closed else 1):]:
+            cv_line8(img, p0, p, color)
+            p0 = p
+
+
+def draw_flow_numpy(img_shape, flow, step=14):
+    """draw_flow (DenseOF.py:40-59 = pathfinder_viewer.py:51-73), re-typed: NumPy lines by the real NumPy, cv2.polylines and
+    cv2.circle by the restatements above."""
+    h, w = img_shape
+    img_bgr = np.zeros((h, w, 3), np.uint8)
+    y, x = np.mgrid[step / 2:h:step, step / 2:w:step].reshape(2, -1).astype(int)
+    fx, fy = flow[y, x].T
+
+    lines = np.vstack([x, y, x - fx, y - fy]).T.reshape(-1, 2, 2)
+    lines = np.int32(lines + 0.5)
+
+    cv_polylines(img_bgr, lines, False, (0, 255, 0))
+
+    for (x1, y1), (_x2, _y2) in lines:
+        cv_circle_filled(img_bgr, (x1, y1), 1, (0, 255, 0))
+
+    return img_bgr
+
+
 def draw_sparse_lamps_numpy(flow_, points_, width, height, radius=6):
     """draw_sparse_lamps (pathfinder_viewer.py:196-222), re-typed: NumPy lines by the real NumPy, HSV2BGR and cv2.circle by the
     restatements above.  flow_, points_: the kept int32 vectors and points get_flow_lk returns (:175-176)."""

@@ -655,6 +655,31 @@ def test_draw_sparse_lamps_bit_exact(H, oracle, h, w, step, radius):
         np.testing.assert_array_equal(d_out[1:].cpu().numpy().reshape(h, w, 3), ref)
 
 
+@pytest.mark.parametrize("h,w,step,scale", [(120, 160, 14, 9), (1080, 1920, 14, 12), (100, 150, 15, 40), (33, 47, 7, 300), (20, 20, 30, 5),
+                                             (64, 64, 1, 3)])
+def test_draw_flow_image_bit_exact(H, oracle, h, w, step, scale):
+    """draw_flow as the reference returns it (DenseOF.py:40-59): the BGR layer with every arrow rasterised as cv2.polylines draws it
+    (clipLine + 8-connected LineIterator) and the radius-1 disc of cv2.circle at its start; flows long enough to leave the image
+    exercise the clipping.  Reference side: the function's own lines with the cv2 calls restated (parity unpinned, like all of OpenCV)."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(h + w + step)
+    flow = (rng.standard_normal((h, w, 2)) * scale).astype(np.float32)
+    flow[h // 2, w // 2] = (3e4, -2e4)
+    ref = oracle.draw_flow_numpy((h, w), flow, step)
+    got = H.draw_flow((h, w), flow, step)
+    assert got.dtype == np.uint8 and got.shape == (h, w, 3)
+    np.testing.assert_array_equal(got, ref)
+    base = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    with H.FarnebackEngine(w, h, 1) as eng:
+        np.testing.assert_array_equal(eng.draw_flow(flow, step, base=base), oracle.cv_add_u8(base, ref))   # DenseOF.py:574
+        d_flow = torch.from_numpy(np.stack([flow, -flow])).cuda()
+        d_img = torch.from_numpy(np.stack([base, base])).cuda()
+        eng.draw_flow_device(d_flow, 2, w, h, d_img, step=step, d_base=d_img)                             # in place, two frames
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(d_img[0].cpu().numpy(), oracle.cv_add_u8(base, ref))
+        np.testing.assert_array_equal(d_img[1].cpu().numpy(), oracle.cv_add_u8(base, oracle.draw_flow_numpy((h, w), -flow, step)))
+
+
 @pytest.mark.parametrize("shape", [(1080, 1920, 3), (37, 53, 3), (5,), (0,), (64, 64)])
 def test_add_u8_is_cv2_add(H, oracle, shape):
     """cv2.add on uint8 (how the viewers stack layers onto the frame, DenseOF.py:574-582): saturating, any size and alignment."""

@@ -382,6 +382,11 @@ def test_view_turn_returns_what_the_viewer_draws(H, oracle):
             np.testing.assert_array_equal(res["v"], v)
             np.testing.assert_array_equal(res["lines"], eng.flow_arrows(flow, 14))
             np.testing.assert_array_equal(res["rainbow"], eng.flow_hsv(flow))
+            # draw_flow's image of the turn (the arrows rasterised), alone and on the turn's own frame (DenseOF.py:574)
+            arrows = oracle.draw_flow_numpy((h, w), flow, 14)
+            np.testing.assert_array_equal(st.view_arrows(14), arrows)
+            if i % 2 == 0:
+                np.testing.assert_array_equal(st.view_arrows(14, over_frame=True), oracle.cv_add_u8(bgr[i], arrows))
             # the rainbow again, after the fact, alone and added onto the turn's own frame (DenseOF.py:577-578)
             np.testing.assert_array_equal(st.view_rainbow(), res["rainbow"])
             if i % 2 == 0:

@@ -192,3 +192,40 @@ def test_draw_sparse_lamps_numpy_known_case(oracle):
     assert bgr[10, 40].tolist() == [0, 0, 50] and bgr[4, 70].tolist() == [0, 0, 255] and bgr[3, 70].tolist() == [0, 0, 0]
     assert int((bgr[..., 2] > 0).sum()) == 3 * int((bgr[..., 2] == 60).sum())
     np.testing.assert_array_equal(oracle.cv_add_u8(np.full_like(bgr, 250), bgr)[10, 10], [250, 250, 255])
+
+
+def test_cv_line8_raster_known_cases(oracle):
+    """The restated cv2.line raster: end points included, 8-connected, one pixel per major-axis step, the same pixels whichever end is
+    given first (leftToRight), and clipping that keeps only the visible part."""
+    def pix(p1, p2, shape=(9, 12)):
+        img = np.zeros(shape, np.uint8)
+        oracle.cv_line8(img, p1, p2, 1)
+        return sorted(zip(*np.nonzero(img)[::-1]))
+    assert pix((1, 1), (6, 1)) == [(x, 1) for x in range(1, 7)]
+    assert pix((2, 0), (2, 5)) == [(2, y) for y in range(6)]
+    assert pix((0, 0), (5, 5)) == [(i, i) for i in range(6)]
+    assert pix((3, 3), (3, 3)) == [(3, 3)]
+    got = pix((0, 0), (10, 3))
+    assert len(got) == 11 and got[0] == (0, 0) and got[-1] == (10, 3) and [x for x, _ in got] == list(range(11))
+    assert all(abs(y - 0.3 * x) <= 0.5 + 1e-9 for x, y in got)
+    for p1, p2 in (((0, 0), (10, 3)), ((1, 7), (9, 2)), ((4, 0), (6, 8)), ((11, 8), (0, 0))):
+        assert pix(p1, p2) == pix(p2, p1)
+    # clipped: a line through the image from outside to outside, one leaving it, one that misses it
+    across = pix((-5, 4), (20, 4))
+    assert across == [(x, 4) for x in range(12)]
+    assert pix((3, 3), (3, 40)) == [(3, y) for y in range(3, 9)]
+    assert pix((-3, -3), (-1, 20)) == [] and pix((14, 2), (30, 5)) == []
+    ok, a, b = oracle.cv_clip_line(12, 9, (-4, -4), (30, 30))
+    assert ok and a == (0, 0) and b == (8, 8)
+
+
+def test_draw_flow_numpy_known_case(oracle):
+    flow = np.zeros((28, 42, 2), np.float32)
+    flow[7, 7] = (-5, 0)                 # drawn from (7, 7) to (12, 7)
+    flow[21, 35] = (100, 0)              # leaves the image on the left: clipped at x = 0
+    img = oracle.draw_flow_numpy((28, 42), flow, 14)
+    assert img[..., 0].sum() == 0 and img[..., 2].sum() == 0 and set(np.unique(img[..., 1])) == {0, 255}
+    g = img[..., 1] > 0
+    assert g[7, 6:13].all() and not g[7, 13] and g[6, 7] and g[8, 7]            # the line, the radius-1 disc at its start
+    assert g[21, 0:37].all() and not g[21, 37]
+    assert g[7, 21] and g[6, 21] and g[7, 20] and g[7, 22] and not g[6, 20]      # zero flow: just the disc
