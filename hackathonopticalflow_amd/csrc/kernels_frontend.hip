@@ -353,6 +353,50 @@ __device__ __forceinline__ bool cv_clip_line(long long right, long long bottom, 
     return (c1 | c2) == 0;
 }
 
+// Line(img, pt1, pt2): clip if an end point lies outside, then LineIterator(pt1, pt2, 8, leftToRight = true); `put(x, y)` per pixel
+template <typename Put>
+__device__ __forceinline__ void cv_raster_line(int w, int h, int ax, int ay, int bx, int by, Put put)
+{
+    long long x1 = ax, y1 = ay, x2 = bx, y2 = by;
+    if ((unsigned long long)x1 >= (unsigned long long)w || (unsigned long long)x2 >= (unsigned long long)w ||
+        (unsigned long long)y1 >= (unsigned long long)h || (unsigned long long)y2 >= (unsigned long long)h)
+        if (!cv_clip_line(w - 1, h - 1, x1, y1, x2, y2)) return;
+    int px = (int)x1, py = (int)y1;
+    int dx = (int)(x2 - x1), dy = (int)(y2 - y1);
+    int delta_x = 1, delta_y = 1;
+    if (dx < 0) { dx = -dx; dy = -dy; px = (int)x2; py = (int)y2; }          // leftToRight: start from the other end
+    if (dy < 0) { dy = -dy; delta_y = -1; }
+    const bool vert = dy > dx;
+    if (vert) { const int t = dx; dx = dy; dy = t; }
+    // 8-connected: the major axis advances every step, the minor one when err < 0
+    int err = dx - (dy + dy);
+    const int plus_delta = dx + dx, minus_delta = -(dy + dy);
+    const int major_x = vert ? 0 : delta_x, major_y = vert ? delta_y : 0;
+    const int minor_x = vert ? delta_x : 0, minor_y = vert ? 0 : delta_y;
+    const int count = dx + 1;
+    for (int k = 0; k < count; k++) {
+        if ((unsigned)px < (unsigned)w && (unsigned)py < (unsigned)h) put(px, py);
+        const int mask = err < 0 ? -1 : 0;
+        err += minus_delta + (plus_delta & mask);
+        px += major_x + (minor_x & mask);
+        py += major_y + (minor_y & mask);
+    }
+}
+
+// cv2.circle(img, (cx, cy), 1, colour, thickness): Circle()'s radius-1 raster is the four neighbours of the centre, plus the centre
+// itself when filled (thickness < 0)
+template <typename Put>
+__device__ __forceinline__ void cv_raster_circle1(int w, int h, int cx, int cy, bool filled, Put put)
+{
+    const int ox[5] = {-1, 1, 0, 0, 0}, oy[5] = {0, 0, -1, 1, 0};
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        if (k == 4 && !filled) break;
+        const int qx = cx + ox[k], qy = cy + oy[k];
+        if ((unsigned)qx < (unsigned)w && (unsigned)qy < (unsigned)h) put(qx, qy);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_draw_flow(const float2 *__restrict__ flow, int w, int h, int npairs, int nx, int ny,
                                                    double start, double step, uint8_t *__restrict__ out)
 {
@@ -367,41 +411,31 @@ __global__ __launch_bounds__(256) void k_draw_flow(const float2 *__restrict__ fl
     const int ax = (int32_t)((double)gx + 0.5), ay = (int32_t)((double)gy + 0.5);
     const int bx = (int32_t)(((double)gx - (double)f.x) + 0.5), by = (int32_t)(((double)gy - (double)f.y) + 0.5);
     uint8_t *img = out + (size_t)p * w * h * 3;
-    // Line(): clip if an end point lies outside, then LineIterator(pt1, pt2, 8, leftToRight = true)
-    long long x1 = ax, y1 = ay, x2 = bx, y2 = by;
-    bool draw = true;
-    if ((unsigned long long)x1 >= (unsigned long long)w || (unsigned long long)x2 >= (unsigned long long)w ||
-        (unsigned long long)y1 >= (unsigned long long)h || (unsigned long long)y2 >= (unsigned long long)h)
-        draw = cv_clip_line(w - 1, h - 1, x1, y1, x2, y2);
-    if (draw) {
-        int px = (int)x1, py = (int)y1;
-        int dx = (int)(x2 - x1), dy = (int)(y2 - y1);
-        int delta_x = 1, delta_y = 1;
-        if (dx < 0) { dx = -dx; dy = -dy; px = (int)x2; py = (int)y2; }          // leftToRight: start from the other end
-        if (dy < 0) { dy = -dy; delta_y = -1; }
-        const bool vert = dy > dx;
-        if (vert) { const int t = dx; dx = dy; dy = t; }
-        // 8-connected: the major axis advances every step, the minor one when err < 0
-        int err = dx - (dy + dy);
-        const int plus_delta = dx + dx, minus_delta = -(dy + dy);
-        const int major_x = vert ? 0 : delta_x, major_y = vert ? delta_y : 0;
-        const int minor_x = vert ? delta_x : 0, minor_y = vert ? 0 : delta_y;
-        const int count = dx + 1;
-        for (int k = 0; k < count; k++) {
-            if ((unsigned)px < (unsigned)w && (unsigned)py < (unsigned)h) img[((size_t)py * w + px) * 3 + 1] = 255;
-            const int mask = err < 0 ? -1 : 0;
-            err += minus_delta + (plus_delta & mask);
-            px += major_x + (minor_x & mask);
-            py += major_y + (minor_y & mask);
-        }
-    }
-    // cv2.circle(img, (x1, y1), 1, colour, -1): the filled radius-1 raster is the centre and its four neighbours
-    const int cx[5] = {0, -1, 1, 0, 0}, cy[5] = {0, 0, 0, -1, 1};
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const int qx = ax + cx[k], qy = ay + cy[k];
-        if ((unsigned)qx < (unsigned)w && (unsigned)qy < (unsigned)h) img[((size_t)qy * w + qx) * 3 + 1] = 255;
-    }
+    auto put = [&](int x, int y) { img[((size_t)y * w + x) * 3 + 1] = 255; };
+    cv_raster_line(w, h, ax, ay, bx, by, put);
+    cv_raster_circle1(w, h, ax, ay, true, put);
+}
+
+// One drawing pass of get_flow_lk's frame layer (pathfinder_viewer.py:180-192): for every grid point whose mask equals `want`, either
+// the line from the point to point + flow (cv2.polylines) or the radius-1 circle outline at the point (cv2.circle, thickness 1), in one
+// colour.  The passes of the reference follow one another (kept lines, kept circles, rejected lines, rejected circles); within a pass
+// every writer stores the same colour, so the order inside it does not matter.
+__global__ __launch_bounds__(256) void k_draw_vectors(const int2 *__restrict__ pts, const int2 *__restrict__ iflow,
+                                                      const uint8_t *__restrict__ mask, int P, int n, int w, int h, int want, int circles,
+                                                      int cb, int cg, int cr, uint8_t *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)P * n) return;
+    if ((mask[i] != 0) != (want != 0)) return;
+    const int p = (int)(i / P);
+    const int2 a = pts[i % P], f = iflow[i];
+    uint8_t *img = out + (size_t)p * w * h * 3;
+    auto put = [&](int x, int y) {
+        uint8_t *q = img + ((size_t)y * w + x) * 3;
+        q[0] = (uint8_t)cb; q[1] = (uint8_t)cg; q[2] = (uint8_t)cr;
+    };
+    if (circles) cv_raster_circle1(w, h, a.x, a.y, false, put);
+    else cv_raster_line(w, h, a.x, a.y, a.x + f.x, a.y + f.y, put);
 }
 
 void launch_draw_flow(hipStream_t s, const float *flow, int w, int h, int npairs, int nx, int ny, double start, double step, uint8_t *out)
@@ -410,6 +444,21 @@ void launch_draw_flow(hipStream_t s, const float *flow, int w, int h, int npairs
     if (n == 0) return;
     hipLaunchKernelGGL(k_draw_flow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float2 *>(flow), w, h,
                        npairs, nx, ny, start, step, out);
+}
+
+void launch_draw_vectors(hipStream_t s, const int *pts, const int32_t *iflow, const uint8_t *mask, int P, int n, int w, int h,
+                         int draw_bad, uint8_t *out)
+{
+    if ((size_t)P * n == 0) return;
+    const dim3 grid((unsigned)(((size_t)P * n + 255) / 256));
+    const int2 *p2 = reinterpret_cast<const int2 *>(pts), *f2 = reinterpret_cast<const int2 *>(iflow);
+    // pathfinder_viewer.py:183-192: red lines, magenta circles; with draw_bad_flow the rejected vectors in (255, 255, 0) after them
+    hipLaunchKernelGGL(k_draw_vectors, grid, dim3(256), 0, s, p2, f2, mask, P, n, w, h, 1, 0, 0, 0, 255, out);
+    hipLaunchKernelGGL(k_draw_vectors, grid, dim3(256), 0, s, p2, f2, mask, P, n, w, h, 1, 1, 255, 0, 255, out);
+    if (draw_bad) {
+        hipLaunchKernelGGL(k_draw_vectors, grid, dim3(256), 0, s, p2, f2, mask, P, n, w, h, 0, 0, 255, 255, 0, out);
+        hipLaunchKernelGGL(k_draw_vectors, grid, dim3(256), 0, s, p2, f2, mask, P, n, w, h, 0, 1, 255, 255, 0, out);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -210,5 +210,50 @@ int ofarn_vector_filter(ofarn_ctx *c, const float *h_vecs, int n, int w, int h, 
     return OFARN_OK;
 }
 
+int ofarn_draw_vectors_device(ofarn_ctx *c, const int32_t *d_iflow, const uint8_t *d_mask, int n, int w, int h, int draw_bad,
+                              uint8_t *d_out, void *hip_stream)
+{
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    if (!d_out) return fail(OFARN_E_INVALID, "out is NULL");
+    if (n < 0) return fail(OFARN_E_INVALID, "n < 0");
+    if (n == 0) return OFARN_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = make_plan(c, w, h))) return rc;
+    if (c->P > 0 && (!d_iflow || !d_mask)) return fail(OFARN_E_INVALID, "iflow and mask must not be NULL");
+    hipStream_t s = pick_stream(c, hip_stream);
+    HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)n * w * h * 3, s));
+    if (c->P > 0) launch_draw_vectors(s, c->d_pts, d_iflow, d_mask, c->P, n, w, h, draw_bad, d_out);
+    HIP_TRY(hipGetLastError());
+    return OFARN_OK;
+}
+
+int ofarn_draw_vectors(ofarn_ctx *c, const int32_t *h_iflow, const uint8_t *h_mask, int n, int w, int h, int draw_bad, uint8_t *h_out)
+{
+    int rc = check_size(c, w, h);
+    if (rc) return rc;
+    if (!h_out) return fail(OFARN_E_INVALID, "out is NULL");
+    if (n < 0) return fail(OFARN_E_INVALID, "n < 0");
+    if (n == 0) return OFARN_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = make_plan(c, w, h))) return rc;
+    const size_t P = (size_t)c->P, img = (size_t)w * h * 3;
+    if (P > 0 && (!h_iflow || !h_mask)) return fail(OFARN_E_INVALID, "iflow and mask must not be NULL");
+    DevTmp ifl, mk, out;
+    if ((rc = ifl.alloc(P * 8 + 8)) || (rc = mk.alloc(P + 8)) || (rc = out.alloc(img))) return rc;
+    for (int i = 0; i < n; i++) {
+        if (P > 0) {
+            HIP_TRY(hipMemcpyAsync(ifl.p, h_iflow + (size_t)i * P * 2, P * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(mk.p, h_mask + (size_t)i * P, P, hipMemcpyHostToDevice, c->stream));
+        }
+        HIP_TRY(hipMemsetAsync(out.p, 0, img, c->stream));
+        if (P > 0) launch_draw_vectors(c->stream, c->d_pts, ifl.as<int32_t>(), mk.as<uint8_t>(), c->P, 1, w, h, draw_bad, out.as<uint8_t>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_out + (size_t)i * img, out.p, img, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return OFARN_OK;
+}
+
 #pragma GCC visibility pop
 }  // extern "C"

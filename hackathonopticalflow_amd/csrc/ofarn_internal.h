@@ -130,6 +130,10 @@ void launch_resize_area(hipStream_t s, const float *src, int sw, int sh, float *
 void launch_flow_hsv(hipStream_t s, const float *flow, size_t npx, uint8_t *hsv, uint8_t *bgr, const uint8_t *base = nullptr);
 // draw_flow as an image: sets the G byte of every pixel cv2.polylines / cv2.circle would draw; `out` uint8[npairs][h][w][3] initialised by the caller
 void launch_draw_flow(hipStream_t s, const float *flow, int w, int h, int npairs, int nx, int ny, double start, double step, uint8_t *out);
+// get_flow_lk's frame layer: lines point -> point + iflow and radius-1 circle outlines for the kept (and, draw_bad, the rejected) grid
+// points into `out` uint8[n][h][w][3], initialised by the caller; pts int[P][2], iflow int32[n][P][2], mask uint8[n][P]
+void launch_draw_vectors(hipStream_t s, const int *pts, const int32_t *iflow, const uint8_t *mask, int P, int n, int w, int h,
+                         int draw_bad, uint8_t *out);
 // cv2.add on uint8: out = saturate(a + b), n bytes
 void launch_add_u8(hipStream_t s, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
 void launch_hsv2bgr(hipStream_t s, const uint8_t *hsv, size_t npx, uint8_t *bgr);

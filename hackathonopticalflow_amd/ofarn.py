@@ -127,6 +127,9 @@ ABI = {
                                          C.c_void_p, C.c_void_p]),
     "ofarn_stream_view_flow": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ofarn_stream_view_lamps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ofarn_draw_vectors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ofarn_draw_vectors_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_void_p]),
     "ofarn_stream_view_arrows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ofarn_draw_flow": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ofarn_draw_flow_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -705,6 +708,30 @@ class FarnebackEngine:
         if return_flow:
             return (mask[0], val[0], iflow[0]) if single else (mask, val, iflow)
         return (mask[0], val[0]) if single else (mask, val)
+
+    def draw_vectors(self, iflow, mask, shape, draw_bad_flow=False):
+        """The frame layer of get_flow_lk (pathfinder_viewer.py:180-192): BGR uint8[H,W,3] (or a stack) with the kept vectors as red
+        lines + magenta start circles, the rejected ones after them in (255, 255, 0) if draw_bad_flow.  iflow int32[P,2] (or
+        [n,P,2]) and mask uint8[P] ([n,P]) as vector_filter(..., return_flow=True) / danger_map(..., return_flow=True) give them."""
+        h, w = int(shape[0]), int(shape[1])
+        f = np.ascontiguousarray(iflow, np.int32)
+        m = np.ascontiguousarray(mask, np.uint8)
+        single = m.ndim == 1
+        if single:
+            f, m = f[None], m[None]
+        P = len(grid_points(w, h, self.params.grid_step))
+        if m.ndim != 2 or m.shape[1] != P or f.shape != m.shape + (2,):
+            raise ValueError(f"iflow must be int32[...,{P},2] and mask uint8[...,{P}] for {w}x{h} frames, got {f.shape} and {m.shape}")
+        out = np.empty((m.shape[0], h, w, 3), np.uint8)
+        _check(self._lib.ofarn_draw_vectors(self._h, C.c_void_p(f.ctypes.data), C.c_void_p(m.ctypes.data), m.shape[0], w, h,
+                                            1 if draw_bad_flow else 0, C.c_void_p(out.ctypes.data)))
+        return out[0] if single else out
+
+    def draw_vectors_device(self, d_iflow, d_mask, n, width, height, d_out, draw_bad_flow=False, stream=None):
+        P = len(grid_points(width, height, self.params.grid_step))
+        _check(self._lib.ofarn_draw_vectors_device(self._h, _ptr(d_iflow, "d_iflow", "int32", n * P * 2), _ptr(d_mask, "d_mask", "uint8", n * P),
+                                                   n, width, height, 1 if draw_bad_flow else 0,
+                                                   _ptr(d_out, "d_out", "uint8", n * width * height * 3), _stream_arg(stream)))
 
     def vector_filter_device(self, d_vecs, n, width, height, d_mask, d_v, d_iflow=None, stream=None):
         P = len(grid_points(width, height, self.params.grid_step))
@@ -1440,10 +1467,11 @@ def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 2
     return nxt.reshape(shape), st.reshape(-1, 1), err.reshape(-1, 1)
 
 
-def get_flow_lk(img1, img2, points_, device=0):
-    """pathfinder_viewer.py:144-201 ``get_flow_lk`` without the drawing: LK from img2 back to img1 at the grid points
-    (winSize 45, maxLevel 2, 10 iterations / 0.03), equalised moduli, median / 99-percentile gate.
-    Returns (None, flow int32[K,2], points_ int32[K,2]) -- the reference's frame_layer is host drawing of those."""
+def get_flow_lk(img1, img2, points_, device=0, draw_bad_flow=False):
+    """pathfinder_viewer.py:144-194 ``get_flow_lk``: LK from img2 back to img1 at the grid points (winSize 45, maxLevel 2,
+    10 iterations / 0.03), equalised moduli, median / 99-percentile gate, and the frame layer with the kept vectors drawn (red lines,
+    magenta start circles; the rejected ones in (255, 255, 0) with draw_bad_flow, the reference's global of that name).
+    Returns (frame_layer uint8[H,W,3], flow int32[K,2], points_ int32[K,2])."""
     a = _as_gray(img1, "img1")
     h, w = a.shape
     pts = np.ascontiguousarray(np.asarray(points_, np.float32).reshape(-1, 2))
@@ -1454,8 +1482,9 @@ def get_flow_lk(img1, img2, points_, device=0):
         nxt, _st, _err = eng.lk(img2, img1, pts, None, winSize=(45, 45), maxLevel=2,
                                 criteria=(TERM_CRITERIA_EPS | TERM_CRITERIA_COUNT, 10, 0.03))
         mask, _v, iflow = eng.vector_filter(nxt - pts, w, h, return_flow=True)
+        layer = eng.draw_vectors(iflow, mask, (h, w), draw_bad_flow)
     keep = mask.astype(bool)
-    return None, iflow[keep], np.int32(pts + 0.5)[keep]
+    return layer, iflow[keep], np.int32(pts + 0.5)[keep]
 
 
 def cvtColor_bgr2gray(img, device=0):

@@ -262,6 +262,13 @@ int ofarn_vector_filter(ofarn_ctx *ctx, const float *h_vecs, int n, int w, int h
                         uint8_t *h_v, int32_t *h_iflow);
 int ofarn_vector_filter_device(ofarn_ctx *ctx, const float *d_vecs, int n, int w, int h, uint8_t *d_mask,
                                uint8_t *d_v, int32_t *d_iflow, void *hip_stream);
+/* The frame layer get_flow_lk returns (pathfinder_viewer.py:147, 180-192): BGR uint8[n][h][w][3], black but for the kept vectors --
+ * cv2.polylines(layer, lines, False, (0, 0, 255)) from each kept grid point to point + iflow, then cv2.circle(layer, point, 1,
+ * (255, 0, 255), 1) -- and, with draw_bad != 0 (the viewer's key 4), the rejected ones after them in (255, 255, 0).  iflow, mask:
+ * what ofarn_vector_filter / ofarn_grid_filter return (iflow is defined at every grid point).  Stack it onto the frame with ofarn_add_u8. */
+int ofarn_draw_vectors(ofarn_ctx *ctx, const int32_t *h_iflow, const uint8_t *h_mask, int n, int w, int h, int draw_bad, uint8_t *h_out);
+int ofarn_draw_vectors_device(ofarn_ctx *ctx, const int32_t *d_iflow, const uint8_t *d_mask, int n, int w, int h, int draw_bad,
+                              uint8_t *d_out, void *hip_stream);
 
 /* ---- multi-GPU in one process -------------------------------------------------------
  * The reference processes one pair per loop turn with no state beyond prev_gray (DenseOF.py:519-525), so pairs are independent

@@ -470,14 +470,20 @@ def draw_hsv_numpy(flow_, cr=True):
     return hsv2bgr_u8(draw_hsv_planes_numpy(flow_, cr=cr))
 
 
-def cv_circle_filled(img, center, radius, color):
+def cv_circle_filled(img, center, radius, color, fill=True):
     """cv2.circle(img, center, radius, color, thickness=-1), lineType LINE_8, shift 0: drawing.cpp Circle() -- a midpoint loop that
-    fills the spans [cx-dx, cx+dx] on rows cy+-dy and [cx-dy, cx+dy] on rows cy+-dx, clipped to the image.  In place."""
+    fills the spans [cx-dx, cx+dx] on rows cy+-dy and [cx-dy, cx+dy] on rows cy+-dx, clipped to the image.  In place.
+    fill=False: thickness=1, the same loop putting only the span end points (the 8 symmetric points of each step)."""
     h, w = img.shape[:2]
     cx, cy = int(center[0]), int(center[1])
 
     def hline(y, x1, x2):
         if 0 <= y < h:
+            if not fill:
+                for x in (x1, x2):
+                    if 0 <= x < w:
+                        img[y, x] = color
+                return
             x1, x2 = max(x1, 0), min(x2, w - 1)
             if x1 <= x2:
                 img[y, x1:x2 + 1] = color
@@ -687,3 +693,25 @@ def get_flow_lk_numpy(img1, img2, points_, width, height, sum_mode=LK_SUM_SCALAR
     flow_ = next_pts - points_
     mask, _mod, iflow, ipts = vector_filter_numpy(flow_, points_, width, height, 0)
     return mask, iflow, ipts, next_pts
+
+
+def get_flow_lk_layer_numpy(mask, iflow, ipts, width, height, draw_bad_flow=False):
+    """The drawing part of get_flow_lk (pathfinder_viewer.py:147, 177-192), re-typed, on the filter's results for ALL points (mask
+    bool[P], iflow = next_pts - points_ int32[P,2], ipts int32[P,2]): cv2.polylines / cv2.circle by the restatements above."""
+    frame_layer = np.zeros((height, width, 3), np.uint8)
+    mask = np.asarray(mask, bool)
+    next_all = ipts + iflow
+    points_, points_bad = ipts[mask], ipts[~mask]
+    next_pts, nextPts_bad = next_all[mask], next_all[~mask]
+    lines = np.concatenate((points_, next_pts), axis=1)
+    rlines = lines.reshape(-1, 2, 2)
+    cv_polylines(frame_layer, rlines, False, (0, 0, 255))
+    for x1, y1, _x2, _y2 in lines:
+        cv_circle_filled(frame_layer, (x1, y1), 1, (255, 0, 255), fill=False)
+    if draw_bad_flow:
+        lines_bad = np.concatenate((points_bad, nextPts_bad), axis=1)
+        rlines_bad = lines_bad.reshape(-1, 2, 2)
+        cv_polylines(frame_layer, rlines_bad, False, (255, 255, 0))
+        for x1, y1, _x2, _y2 in lines_bad:
+            cv_circle_filled(frame_layer, (x1, y1), 1, (255, 255, 0), fill=False)
+    return frame_layer

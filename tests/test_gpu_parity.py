@@ -826,9 +826,40 @@ def test_lk_batch_device_and_get_flow_lk(H, oracle):
     ref_n, _, _ = oracle.calc_optical_flow_pyr_lk(frames[1], frames[0], pts, None, winSize=(45, 45), maxLevel=2,
                                                   criteria=(10, 0.03), sum_mode=oracle.LK_SUM_COLUMNS)
     mask, iflow, ipts, _ = oracle.get_flow_lk_numpy(frames[0], frames[1], pts, w, h, next_pts=ref_n)
-    assert layer is None and flow.dtype == np.int32
+    assert flow.dtype == np.int32
     np.testing.assert_array_equal(kept, ipts[mask])
     np.testing.assert_array_equal(flow, iflow[mask])
+    # the frame layer: kept vectors as red lines with magenta start circles; with the viewer's key 4 the rejected ones too
+    np.testing.assert_array_equal(layer, oracle.get_flow_lk_layer_numpy(mask, iflow, ipts, w, h))
+    layer_bad, _, _ = H.get_flow_lk(frames[0], frames[1], pts, draw_bad_flow=True)
+    np.testing.assert_array_equal(layer_bad, oracle.get_flow_lk_layer_numpy(mask, iflow, ipts, w, h, draw_bad_flow=True))
+    assert (layer_bad != layer).any() and set(map(tuple, layer.reshape(-1, 3))) <= {(0, 0, 0), (0, 0, 255), (255, 0, 255)}
+
+
+@pytest.mark.parametrize("h,w,step,scale", [(270, 480, 30, 6), (1080, 1920, 30, 25), (61, 75, 20, 200), (40, 40, 3, 4)])
+def test_draw_vectors_layer_bit_exact(H, oracle, h, w, step, scale):
+    """get_flow_lk's drawing on arbitrary vectors: lines that cross, leave the image or have zero length, circles at the border; host
+    and device entry points."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(h * 7 + w)
+    pts = oracle.grid_points_numpy(w, h, step)
+    vec = (rng.standard_normal((len(pts), 2)) * scale).astype(np.float32)
+    vec[::7] = 0
+    mask, _mod, iflow, ipts = oracle.vector_filter_numpy(vec, pts, w, h, 0)
+    with H.FarnebackEngine(w, h, 1, grid_step=step) as eng:
+        m2, _v, if2 = eng.vector_filter(vec, w, h, return_flow=True)
+        np.testing.assert_array_equal(m2.astype(bool), mask)
+        np.testing.assert_array_equal(if2, iflow)
+        for bad in (False, True):
+            ref = oracle.get_flow_lk_layer_numpy(mask, iflow, ipts, w, h, draw_bad_flow=bad)
+            np.testing.assert_array_equal(eng.draw_vectors(if2, m2, (h, w), bad), ref)
+        d_out = torch.empty((2, h, w, 3), dtype=torch.uint8, device="cuda")
+        d_if = torch.from_numpy(np.stack([if2, -if2])).cuda()
+        d_m = torch.from_numpy(np.stack([m2, 1 - m2])).cuda()
+        eng.draw_vectors_device(d_if, d_m, 2, w, h, d_out, draw_bad_flow=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(d_out[0].cpu().numpy(), ref)
+        np.testing.assert_array_equal(d_out[1].cpu().numpy(), oracle.get_flow_lk_layer_numpy(~mask, -iflow, ipts, w, h, draw_bad_flow=True))
 
 
 def test_lk_1080p_grid(H, oracle):

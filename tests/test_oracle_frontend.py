@@ -229,3 +229,14 @@ def test_draw_flow_numpy_known_case(oracle):
     assert g[7, 6:13].all() and not g[7, 13] and g[6, 7] and g[8, 7]            # the line, the radius-1 disc at its start
     assert g[21, 0:37].all() and not g[21, 37]
     assert g[7, 21] and g[6, 21] and g[7, 20] and g[7, 22] and not g[6, 20]      # zero flow: just the disc
+
+
+def test_cv_circle_outline_radius_one(oracle):
+    img = np.zeros((5, 5), np.uint8)
+    oracle.cv_circle_filled(img, (2, 2), 1, 1, fill=False)
+    assert sorted(zip(*np.nonzero(img))) == [(1, 2), (2, 1), (2, 3), (3, 2)]          # thickness 1: the four neighbours, not the centre
+    big = np.zeros((21, 21), np.uint8)
+    oracle.cv_circle_filled(big, (10, 10), 8, 1, fill=False)
+    full = np.zeros((21, 21), np.uint8)
+    oracle.cv_circle_filled(full, (10, 10), 8, 1)
+    assert big.sum() < full.sum() and not (big & ~full).any() and big[10, 2] and big[2, 10] and not big[10, 10]
