@@ -87,15 +87,24 @@ def algorithmic_bytes_per_pair(w, h, plan, iterations):
 def self_launch(args, argv):
     """--gpus N > 1 outside torch.distributed.run: start the ranks as a fresh child.  Nothing in this process has
     touched HIP yet (torch is not even imported), and the child is a new process, not an exec of this one."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={max(args.gpus, 1)}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
-    return subprocess.run(cmd, env=env).returncode
+    rc = 1
+    for attempt in range(3):
+        # a port that is free now can be taken by the time the launcher binds it (seen once: EADDRINUSE): a child that dies within
+        # seconds, before any rank has got as far as its timed region, is started again on another port
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={max(args.gpus, 1)}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+        t0 = time.time()
+        rc = subprocess.run(cmd, env=env).returncode
+        if rc == 0 or time.time() - t0 > 20:
+            break
+        print(f"[bench] launcher exited with {rc} after {time.time() - t0:.0f} s (attempt {attempt + 1} of 3)", file=sys.stderr)
+    return rc
 
 
 def smooth_base_gpu(torch, hh, ww, seed, device, sigma=4.0):
