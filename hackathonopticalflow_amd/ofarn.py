@@ -1249,7 +1249,9 @@ class _PinnedPool:
     MAX_BYTES = 1 << 30
 
     def __init__(self):
-        self._lock = threading.Lock()
+        # re-entrant: a block's finalizer (_give_back) can run inside take() on the same thread, when the cyclic collector frees a
+        # result array that sat in a reference cycle while take() allocates
+        self._lock = threading.RLock()
         self._free: dict = {}       # (h, w) -> [address, ...]
         self._live: dict = {}       # (h, w) -> blocks handed out
         self._bytes = 0
