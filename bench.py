@@ -372,6 +372,19 @@ def bench_stream(args, cfg, params):
                 dv.append(stv.last_device_ms)
             view[key] = round(float(np.median(tv)), 4)
             view[key.replace("_ms_per_frame", "_device_ms")] = round(float(np.median(dv)), 4)
+    # the loop through the drop-in itself, as the reference writes it (DenseOF.py:519-525): a NEW gray array per frame, the result
+    # rebound every turn
+    def dropin_loop(n):
+        prev, total = np.array(frames_in[0]), 0.0
+        for i in range(1, n + 1):
+            gray = np.array(frames_in[i % nuniq])              # what cap.read() + cvtColor hand over: a fresh array
+            t0 = time.perf_counter()
+            _flow = ofa.calculate_optical_flow(prev, gray, **params)
+            total += time.perf_counter() - t0
+            prev = gray
+        return total / n * 1e3
+    dropin_loop(max(args.warmup, 12))
+    dropin_ms = dropin_loop(args.steps)
     last_pair = (frames[(args.steps - 1) % nuniq], frames[args.steps % nuniq])
     plan = ofa.level_plan(W, H, **params)
     alg = algorithmic_bytes_per_pair(W, H, plan, params["iterations"])
@@ -389,6 +402,7 @@ def bench_stream(args, cfg, params):
         "pairs_per_s_wall": round(1e3 / float(np.median(ts)), 1),
         "zero_copy": os.environ.get("OFARN_STREAM_ZERO_COPY", "1") != "0",
         "pipelined_ms_per_frame": round(t_p, 4), "pipelined_pairs_per_s_wall": round(1e3 / t_p, 1),
+        "dropin_loop_ms_per_frame": round(dropin_ms, 4),     # flow = calculate_optical_flow(prev_gray, gray); prev_gray = gray
         "view": dict(view, note="synchronous turn returning the danger map + arrow lines (and, second pair of figures, the rainbow image) "
                                 "computed from the flow on the device; the float32 flow field stays in HBM"),
         "roofline": {"bound": "latency (dependent launches on grids of a few blocks) + PCIe (16.6 MB of flow per frame)",
