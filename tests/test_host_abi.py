@@ -227,6 +227,29 @@ def test_multi_gpu_entry_points_without_a_gpu():
     lib.ofarn_multi_destroy(None)
 
 
+def test_drawing_entry_points_reject_a_null_context():
+    """The drawing / stacking entry points of round 3 check their context before anything else: a NULL handle is OFARN_E_INVALID with a
+    message, on a machine without a GPU too (no HIP call has been made by then)."""
+    lib = H.load_library()
+    buf = (ctypes.c_uint8 * 64)()
+    calls = [
+        lambda: lib.ofarn_draw_lamps(None, buf, buf, 1, 8, 8, 2, None, buf),
+        lambda: lib.ofarn_draw_lamps_device(None, buf, buf, 1, 8, 8, 2, None, buf, None),
+        lambda: lib.ofarn_draw_flow(None, buf, 1, 4, 2, 1, None, buf),
+        lambda: lib.ofarn_draw_flow_device(None, buf, 1, 4, 2, 1, None, buf, None),
+        lambda: lib.ofarn_draw_vectors(None, buf, buf, 1, 8, 8, 0, buf),
+        lambda: lib.ofarn_draw_vectors_device(None, buf, buf, 1, 8, 8, 0, buf, None),
+        lambda: lib.ofarn_add_u8(None, buf, buf, 16, buf),
+        lambda: lib.ofarn_add_u8_device(None, buf, buf, 16, buf, None),
+        lambda: lib.ofarn_stream_view_lamps(None, 8, 8, 2, 0, buf),
+        lambda: lib.ofarn_stream_view_rainbow(None, 8, 8, 0, buf),
+        lambda: lib.ofarn_stream_view_arrows(None, 8, 8, 14, 0, buf),
+    ]
+    for call in calls:
+        assert call() == ofarn.OFARN_E_INVALID
+        assert b"NULL" in lib.ofarn_last_error()
+
+
 def test_drop_in_frame_reuse_bookkeeping():
     """The drop-in's reuse rule without a GPU: a slot "holds" a frame only if it is the SAME array object as the last call's `next`
     and its fingerprint (address, shape, strides, checksum of every 16th row) is unchanged; an in-place change to a sampled row, a
