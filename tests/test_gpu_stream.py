@@ -445,6 +445,8 @@ def test_dropin_results_come_from_a_pinned_pool_and_are_never_recycled_while_ref
         assert g.ctypes.data in (a0, fa)                           # a block the caller has let go of is used again
         np.testing.assert_array_equal(g, eng.calc(fr[2], fr[3]))
         # the loop as the reference writes it: the result is rebound every turn, so two blocks alternate
+        del kept, g
+        gc.collect()
         seen, prev = set(), fr[0]
         for i in range(1, 8):
             flow = H.calculate_optical_flow(prev, fr[i])
