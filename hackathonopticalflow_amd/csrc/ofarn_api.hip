@@ -1123,13 +1123,26 @@ int ofarn_calc(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next, int w
     if (use_init)   // cv2: `flow` is an in/out argument holding the initial flow
         HIP_TRY(hipMemcpyAsync(c->st_flow, h_flow, fsz * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    if ((rc = run_wave(c, c->stream, c->st_frames, 1, OFARN_PAIRS_INDEPENDENT, w, h, c->st_flow, nullptr, nullptr, 0,
+    // a page-locked flow buffer (ofarn_host_alloc / hipHostMalloc) is written by the last iteration kernel itself, as in
+    // ofarn_stream_next: no copy behind the kernels ("stream_zero_copy" = 0 switches it off)
+    float *d_out = c->st_flow;
+    bool direct = false;
+    if (!use_init && c->stream_zero_copy) {
+        hipPointerAttribute_t at;
+        void *dp = nullptr;
+        if (hipPointerGetAttributes(&at, h_flow) == hipSuccess && at.type == hipMemoryTypeHost &&
+            hipHostGetDevicePointer(&dp, h_flow, 0) == hipSuccess && dp) {
+            d_out = static_cast<float *>(dp);
+            direct = true;
+        } else (void)hipGetLastError();
+    }
+    if ((rc = run_wave(c, c->stream, c->st_frames, 1, OFARN_PAIRS_INDEPENDENT, w, h, d_out, nullptr, nullptr, 0,
                        use_init ? c->st_flow : nullptr))) {
         (void)end_call(c, c->stream);
         return rc;
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(hipMemcpyAsync(h_flow, c->st_flow, fsz * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (!direct) HIP_TRY(hipMemcpyAsync(h_flow, c->st_flow, fsz * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));

@@ -87,7 +87,8 @@ const char *ofarn_last_error(void);
 
 /* One frame pair, host memory in, host memory out; synchronous.
  * Replaces: cv2.calcOpticalFlowFarneback(prev, next, None, ...) at DenseOF.py:147-156.
- * h_prev/h_next: uint8, `stride` bytes per row.  h_flow: float32[h][w][2], (dx, dy) per pixel. */
+ * h_prev/h_next: uint8, `stride` bytes per row.  h_flow: float32[h][w][2], (dx, dy) per pixel; a page-locked buffer
+ * (ofarn_host_alloc) is written by the last kernel itself, without a copy behind it. */
 int ofarn_calc(ofarn_ctx *ctx, const uint8_t *h_prev, const uint8_t *h_next, int w, int h,
                int stride, float *h_flow);
 

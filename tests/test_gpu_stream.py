@@ -454,3 +454,22 @@ def test_dropin_results_come_from_a_pinned_pool_and_are_never_recycled_while_ref
             np.testing.assert_array_equal(flow, eng.calc(fr[i - 1], fr[i]))
             prev = fr[i]
         assert len(seen) <= 2
+
+
+def test_pair_call_writes_a_pinned_flow_buffer_directly(H, oracle):
+    """ofarn_calc with a page-locked flow buffer: the last kernel writes it itself (no copy behind the kernels), pageable buffers go
+    through the staging copy; both equal the oracle, also with the zero-copy switched off and for a frame that is not at level 0's
+    marching width."""
+    for (w, h, levels) in ((320, 240, 3), (1918, 1078, 5)):
+        a, b, _ = translated_pair(h, w, 91, max_shift=4)
+        ref = oracle.farneback(a, b, levels=levels, box_mode=oracle.BOX_BLOCKED)
+        with H.FarnebackEngine(w, h, 1, levels=levels) as eng:
+            pinned = H.pinned_empty((h, w, 2))
+            pinned[...] = -7
+            out = eng.calc(a, b, pinned)
+            assert out is pinned
+            np.testing.assert_array_equal(out, ref)
+            np.testing.assert_array_equal(eng.calc(a, b), ref)
+            eng.set_option("stream_zero_copy", 0)
+            pinned[...] = -7
+            np.testing.assert_array_equal(eng.calc(a, b, pinned), ref)
