@@ -100,10 +100,20 @@ def self_launch(args, argv):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={max(args.gpus, 1)}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
         t0 = time.time()
-        rc = subprocess.run(cmd, env=env).returncode
-        if rc == 0 or time.time() - t0 > 20:
+        # stderr is passed through AND kept: only a rendezvous port that was taken between the probe above and the launcher's bind
+        # (EADDRINUSE) is worth another attempt; any other failure -- a rank that faults, a bad argument -- is returned as it is
+        proc = subprocess.Popen(cmd, env=env, stderr=subprocess.PIPE, text=True, errors="replace")
+        tail = []
+        for line in proc.stderr:
+            sys.stderr.write(line)
+            tail.append(line)
+            del tail[:-400]
+        rc = proc.wait()
+        err = "".join(tail)
+        if rc == 0 or not ("EADDRINUSE" in err or "address already in use" in err.lower()):
             break
-        print(f"[bench] launcher exited with {rc} after {time.time() - t0:.0f} s (attempt {attempt + 1} of 3)", file=sys.stderr)
+        print(f"[bench] rendezvous port {port} was taken (launcher exited with {rc} after {time.time() - t0:.0f} s); "
+              f"attempt {attempt + 1} of 3", file=sys.stderr)
     return rc
 
 
@@ -427,6 +437,187 @@ def bench_stream(args, cfg, params):
     print(json.dumps(out))
 
 
+def inproc_shards(cfg, n_gpus, batch=None):
+    """Pairs per device for the in-process multi-GPU bench: (global_pairs, [(start, count)] per device).  Config 3 is weak scaling
+    (a fixed batch per GPU), configs 4 and 5 shard a fixed global batch -- exactly ofarn_shard_pairs, which is what ofarn_multi_*
+    uses.  Pure arithmetic (tests/test_distributed_cpu.py)."""
+    from hackathonopticalflow_amd import distributed as D
+    if n_gpus < 1:
+        raise ValueError("n_gpus must be >= 1")
+    global_pairs = (batch or cfg["per_gpu_pairs"]) * n_gpus if "per_gpu_pairs" in cfg else (batch or cfg["global_pairs"])
+    shards = [D.shard_pairs(global_pairs, g, n_gpus) for g in range(n_gpus)]
+    if min(c for _, c in shards) < 1:
+        raise ValueError(f"{global_pairs} pairs cannot be sharded over {n_gpus} devices")
+    return global_pairs, shards
+
+
+def roofline_object(prof, steps, value_per_gpu, W, H, plan, iterations, traffic_tab):
+    """The `roofline` object of the JSON line from one context's per-kernel records (shared by both multi-GPU forms)."""
+    dom = max(prof, key=lambda r: r["ms"])
+    per_launch_s = dom["ms"] / dom["launches"] / 1e3
+    bytes_launch = KERNEL_BYTES.get(dom["stage"], 0.0) * dom["units"] / dom["launches"]
+    ach = bytes_launch / per_launch_s / 1e9
+    survey_launch = STAGE_BYTES.get(dom["stage"], 0.0) * dom["units"] / dom["launches"]
+    traffic = None
+    per_unit = (traffic_tab.get(dom["stage"]) or {}).get("hbm_bytes_per_unit") if dom["level"] == 0 else None
+    if per_unit:
+        traffic = per_unit * dom["units"] / dom["launches"]
+    total_ms = sum(r["ms"] for r in prof)
+    real_pair = traffic_tab.get("pipeline_hbm_bytes_per_pair")
+    alg_pair = algorithmic_bytes_per_pair(W, H, plan, iterations)
+    agg = {}
+    for r in prof:
+        agg[r["stage"]] = agg.get(r["stage"], 0.0) + r["ms"] / steps
+    return {
+        "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "traffic_frac": round(traffic / per_launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+        "kernel": f"{dom['stage']}@level{dom['level']}",
+        "kernel_avg_ms": round(per_launch_s * 1e3, 4), "kernel_launches": dom["launches"],
+        "kernel_share_of_device_time": round(dom["ms"] / total_ms, 4),
+        "algorithmic_bytes_per_launch": bytes_launch,
+        "algorithmic_bytes_per_unit": KERNEL_BYTES.get(dom["stage"]),
+        "survey_8d_bytes_per_launch": survey_launch,
+        "survey_8d_achieved": round(survey_launch / per_launch_s / 1e9, 1),
+        "survey_8d_frac": round(survey_launch / per_launch_s / 1e9 / HBM_PEAK_GBS, 4),
+        "survey_8d_note": "work rate, not a bandwidth: SURVEY 8(d) prices the launch at 96 B/px including 40 B/px of M traffic "
+                          "that the fused kernel never moves, so it can exceed 1; `frac` (56 B/px) and `traffic_frac` (PMC) are the bandwidths",
+        "pipeline": {
+            "algorithmic_bytes_per_pair": alg_pair,
+            "achieved": round(alg_pair * value_per_gpu / 1e9, 1),
+            "frac": round(alg_pair * value_per_gpu / 1e9 / HBM_PEAK_GBS, 4),
+            "real_bytes_per_pair": real_pair,
+            "real_frac": round(real_pair * value_per_gpu / 1e9 / HBM_PEAK_GBS, 4) if real_pair else None,
+        },
+        "stages_ms_per_step": {k: round(val, 3) for k, val in agg.items()},
+    }
+
+
+def bench_inproc(args, cfg, params):
+    """`--multi inproc`: SURVEY 8(e) as written.  ONE process drives N GPUs through the C-ABI's ofarn_multi_* (MultiGpuEngine):
+    device-resident shards in, flow to each device's HBM, the danger maps of ALL pairs all-gathered onto every device by one
+    in-place ncclAllGather group per step -- inside the timed region.  Same JSON schema as the one-process-per-GPU form."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: hackathonopticalflow_amd has no CPU path")
+    import hackathonopticalflow_amd as ofa
+    N = max(args.gpus, 1)
+    ndev = torch.cuda.device_count()
+    if N > ndev:
+        raise SystemExit(f"--gpus {N} but {ndev} GPU(s) visible (one context per GPU)")
+    W, H = cfg["w"], cfg["h"]
+    try:
+        global_pairs, shards = inproc_shards(cfg, N, args.batch)
+    except ValueError as e:
+        raise SystemExit(str(e))
+    cap = max(c for _, c in shards)
+    wave = min(args.wave, cap)
+    eng = ofa.MultiGpuEngine(list(range(N)), W, H, wave, **params)
+    P = len(ofa.grid_points(W, H, 30))
+    plan = ofa.level_plan(W, H, **params)
+    uniq = min(args.unique, global_pairs)
+    frames, flows, masks, vs = [], [], [], []
+    fr_u0 = gt_u0 = None
+    for g, (start, cnt) in enumerate(shards):
+        device = torch.device("cuda", g)
+        with torch.cuda.device(g):
+            fr_u, gt_u = make_frames_gpu(torch, uniq, 3000, device, W, H, args.family)     # the same distinct pairs on every device
+            f = torch.empty((2 * cnt, H, W), dtype=torch.uint8, device=device)
+            for i in range(cnt):
+                j = (start + i) % uniq
+                f[2 * i:2 * i + 2] = fr_u[2 * j:2 * j + 2]
+            frames.append(f)
+            flows.append(torch.empty((cnt, H, W, 2), dtype=torch.float32, device=device))
+            masks.append(torch.zeros((global_pairs, P), dtype=torch.uint8, device=device))
+            vs.append(torch.zeros((global_pairs, P), dtype=torch.uint8, device=device))
+            if g == 0:
+                fr_u0, gt_u0 = fr_u, gt_u
+            else:
+                del fr_u, gt_u
+            torch.cuda.synchronize(g)
+
+    def step():
+        eng.calc_batch_device(frames, global_pairs, W, H, ofa.PAIRS_INDEPENDENT, flows, masks, vs)
+
+    def fence():
+        eng.synchronize()
+
+    def timed_steps(k):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        fence()
+        return time.perf_counter() - t0
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    calls0 = eng.info()["allgather_calls"]
+    if not args.no_profile:
+        eng.rank_profile_enable(0, True)
+    elapsed = timed_steps(args.steps)
+    prof = [] if args.no_profile else eng.rank_profile_read(0)
+    if not args.no_profile:
+        eng.rank_profile_enable(0, False)
+    calls = eng.info()["allgather_calls"] - calls0
+    # the gather really gathered: device g's own rows of the gathered arrays equal what every OTHER device holds for them, and a
+    # single-context run of device 0's shard reproduces its rows
+    gather_ok = True
+    ref_m, ref_v = masks[0].cpu(), vs[0].cpu()
+    for g in range(1, N):
+        gather_ok = gather_ok and bool((masks[g].cpu() == ref_m).all()) and bool((vs[g].cpu() == ref_v).all())
+    with ofa.FarnebackEngine(W, H, min(wave, 8), 0, **params) as single, torch.cuda.device(0):
+        nchk = min(shards[0][1], 8)
+        f1 = torch.empty((nchk, H, W, 2), dtype=torch.float32, device="cuda:0")
+        m1 = torch.zeros((nchk, P), dtype=torch.uint8, device="cuda:0")
+        v1 = torch.zeros_like(m1)
+        single.calc_batch_device(frames[0][:2 * nchk], 2 * nchk, W, H, ofa.PAIRS_INDEPENDENT, f1, m1, v1,
+                                 stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize(0)
+        gather_ok = gather_ok and bool((m1 == masks[0][:nchk]).all()) and bool((v1 == vs[0][:nchk]).all()) \
+            and bool((f1 == flows[0][:nchk]).all())
+        del f1, m1, v1
+    value = global_pairs * args.steps / elapsed
+    res = "1920x1080" if W == 1920 else f"{W}x{H}"
+    if args.config == 3:
+        workload = f"config3: {res} batch={cap} {args.family} smooth-noise pairs per GPU"
+    else:
+        workload = f"config{args.config}: {res} batch={global_pairs} {args.family} smooth-noise pairs in total, {cap} per GPU (sharded)"
+    out = {
+        "metric": f"frame-pairs/s @{'1080p' if W == 1920 else '4K'} ({cfg['levels']}-level, {cfg['iterations']}-iter)",
+        "value": round(value, 2), "unit": "pairs/s",
+        "n_gpus": N, "ranks": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": cfg["scaling"],
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload + f" ({uniq} distinct, tiled), levels={cfg['levels']} iterations={cfg['iterations']} winsize=15 "
+                               f"poly_n=5, f32 with OpenCV's f64 accumulators, flow + danger maps to HBM, the danger maps of all pairs "
+                               f"all-gathered onto every device (in-place ncclAllGather group) inside the timed region",
+                   "pairs_per_gpu": cap, "global_pairs": global_pairs, "wave": wave,
+                   "workspace_bytes_per_gpu": eng.rank_workspace_bytes(0),
+                   "parallelism": f"{N} devices in one process, ncclCommInitAll"},
+        "roofline": roofline_object(prof, args.steps, value / N, W, H, plan, params["iterations"], load_traffic(cfg["key"])) if prof else None,
+        "gathered_danger_maps_checked": gather_ok,
+        "collective": {"backend": "rccl (ncclCommInitAll, in-place ncclAllGather, one group per batch)", "world": N, "calls": int(calls),
+                       "calls_per_step": calls / max(args.steps, 1), "bytes_per_rank": int(2 * cap * P),
+                       "rccl_version": eng.info()["rccl_version"]},
+    }
+    if N == 1 and args.cpu_sample > 0:
+        ns = min(args.cpu_sample, uniq, shards[0][1])
+        npar = min(16, ns)
+        fr_np = fr_u0[:2 * ns].cpu().numpy()
+        cb, ref = cpu_baseline(fr_np, ns, params, args.cpu_threads)
+        out["cpu_baseline"] = cb
+        par = parity_report(ofa, flows[0][:npar].cpu().numpy(), masks[0][:npar].cpu().numpy(), ref[:npar],
+                            [gt_u0[i] for i in range(npar)], W, H, args.family)
+        out["parity"] = par
+        out["mean_epe_vs_cpu_oracle_px"] = par["epe_vs_cpu_oracle"]["mean"]
+        out[f"speedup_vs_cpu_{cb['cores']}_threads"] = round(value / cb["value"], 1)
+        out["speedup_vs_cpu_1_thread"] = round(value / cb["single_thread_value"], 1)
+    print(json.dumps(out))
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -454,6 +645,10 @@ def main():
                     help="run the distributed leg at ANY world size, 1 included: bench.py starts its rank(s) through "
                          "torch.distributed.run, initialises the process group and all-gathers the danger maps inside the timed "
                          "region.  `--gpus 1 --backend nccl --force-dist` is how RCCL's all_gather_into_tensor is exercised on a one-GPU box")
+    ap.add_argument("--multi", default="ranks", choices=["ranks", "inproc"],
+                    help="how N GPUs are driven: 'ranks' = one process per GPU (torch.distributed / RCCL, what the driver launches); "
+                         "'inproc' = SURVEY 8(e) as written: ONE process, ofarn_multi_* (a context + persistent host thread + stream "
+                         "per device, ncclCommInitAll, one in-place ncclAllGather group per batch)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (gloo: rehearsal of the multi-rank path with "
                          "several ranks sharing one GPU; the gather then goes through host memory)")
@@ -465,6 +660,14 @@ def main():
         args.warmup = (40 if args.stream else 5) if args.config == 2 else 2
     if args.steps < 1 or args.warmup < 0 or args.wave < 1 or (args.batch is not None and args.batch < 1):
         raise SystemExit("--steps, --batch and --wave must be >= 1, --warmup >= 0")
+
+    if args.multi == "inproc":
+        if args.config == 2:
+            raise SystemExit("--multi inproc drives batches (configs 3, 4, 5)")
+        if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise SystemExit("--multi inproc is ONE process for all GPUs: start it without torch.distributed.run")
+        params = dict(pyr_scale=0.5, levels=cfg["levels"], winsize=15, iterations=cfg["iterations"], poly_n=5, poly_sigma=1.2, flags=0)
+        return bench_inproc(args, cfg, params)
 
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     if (args.gpus > 1 or args.force_dist) and "RANK" not in os.environ:
@@ -527,15 +730,20 @@ def main():
     flow = torch.empty((B, H, W, 2), dtype=torch.float32, device=device)
     mask = torch.zeros((B, P), dtype=torch.uint8, device=device)
     v = torch.zeros((B, P), dtype=torch.uint8, device=device)
-    stream = torch.cuda.current_stream().cuda_stream
+    # a stream of its own (non-blocking), not torch's legacy null stream: launches on the null stream carry its implicit
+    # synchronisation, which a small latency-bound batch notices (2 pairs of 4K: 4.16 vs 3.08 ms per step, round 4); the
+    # collective is issued under the same stream context, so it is ordered behind the kernels without a device-wide fence
+    tstream = torch.cuda.Stream(device=device)
+    stream = tstream.cuda_stream
     gathered = [None]
     # the one collective of the path, buffers allocated once (device tensors under nccl = RCCL; host tensors under gloo)
     gather = D.DangerGather(global_pairs, P, device if args.backend == "nccl" else "cpu", dist) if dist is not None else None
 
     def step():
-        eng.calc_batch_device(frames, 2 * B, W, H, ofa.PAIRS_INDEPENDENT, flow, mask, v, stream=stream)
-        if gather is not None:
-            gathered[0] = gather(mask.cpu(), v.cpu()) if args.backend == "gloo" else gather(mask, v)
+        with torch.cuda.stream(tstream):
+            eng.calc_batch_device(frames, 2 * B, W, H, ofa.PAIRS_INDEPENDENT, flow, mask, v, stream=stream)
+            if gather is not None:
+                gathered[0] = gather(mask.cpu(), v.cpu()) if args.backend == "gloo" else gather(mask, v)
 
     def fence():
         torch.cuda.synchronize()
@@ -556,6 +764,7 @@ def main():
             el = float(t.item())
         return el
 
+    torch.cuda.synchronize()           # the inputs were made on torch's default stream
     for _ in range(args.warmup):
         step()
     fence()
@@ -602,6 +811,7 @@ def main():
         frames = torch.empty_like(keep)
         for i in range(B):
             frames[2 * i:2 * i + 2] = fr_o[2 * (i % u2):2 * (i % u2) + 2]
+        torch.cuda.synchronize()
         step()
         if not args.no_profile:
             eng.profile_enable(True)
@@ -631,54 +841,11 @@ def main():
                   f"avg={per:8.4f} ms  alg={gbs:8.1f} GB/s", file=sys.stderr)
     pairs_total = global_pairs * args.steps
     value = pairs_total / elapsed
-    alg_pair = algorithmic_bytes_per_pair(W, H, plan, params["iterations"])
     traffic_tab = load_traffic(cfg["key"])
 
-    roofline = None
-    if prof:
-        dom = max(prof, key=lambda r: r["ms"])
-        per_launch_s = dom["ms"] / dom["launches"] / 1e3
-        bytes_launch = KERNEL_BYTES.get(dom["stage"], 0.0) * dom["units"] / dom["launches"]
-        ach = bytes_launch / per_launch_s / 1e9
-        survey_launch = STAGE_BYTES.get(dom["stage"], 0.0) * dom["units"] / dom["launches"]
-        # HBM bytes from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as
-        # MI355X_MICROARCH.md prescribes; provenance inside profiles/pmc_traffic.json), measured per work unit at
-        # level 0 and scaled to this run's units per launch.
-        traffic = None
-        per_unit = (traffic_tab.get(dom["stage"]) or {}).get("hbm_bytes_per_unit") if dom["level"] == 0 else None
-        if per_unit:
-            traffic = per_unit * dom["units"] / dom["launches"]
-        total_ms = sum(r["ms"] for r in prof)
-        real_pair = traffic_tab.get("pipeline_hbm_bytes_per_pair")
-        roofline = {
-            "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "traffic_frac": round(traffic / per_launch_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-            "kernel": f"{dom['stage']}@level{dom['level']}",
-            "kernel_avg_ms": round(per_launch_s * 1e3, 4), "kernel_launches": dom["launches"],
-            "kernel_share_of_device_time": round(dom["ms"] / total_ms, 4),
-            "algorithmic_bytes_per_launch": bytes_launch,
-            "algorithmic_bytes_per_unit": KERNEL_BYTES.get(dom["stage"]),
-            # SURVEY 8(d) charges an iteration 96 B per level pixel (C 68 + D 28) whether or not M goes through HBM; the fused
-            # kernel does not move M, so this figure is a work rate, not a bandwidth, and may exceed the peak
-            "survey_8d_bytes_per_launch": survey_launch,
-            "survey_8d_achieved": round(survey_launch / per_launch_s / 1e9, 1),
-            "survey_8d_frac": round(survey_launch / per_launch_s / 1e9 / HBM_PEAK_GBS, 4),
-            "survey_8d_note": "work rate, not a bandwidth: SURVEY 8(d) prices the launch at 96 B/px including 40 B/px of M traffic "
-                              "that the fused kernel never moves, so it can exceed 1; `frac` (56 B/px) and `traffic_frac` (PMC) are the bandwidths",
-            "pipeline": {
-                "algorithmic_bytes_per_pair": alg_pair,
-                "achieved": round(alg_pair * value / world / 1e9, 1),
-                "frac": round(alg_pair * value / world / 1e9 / HBM_PEAK_GBS, 4),
-                "real_bytes_per_pair": real_pair,
-                "real_frac": round(real_pair * value / world / 1e9 / HBM_PEAK_GBS, 4) if real_pair else None,
-            },
-            "stages_ms_per_step": {},
-        }
-        agg = {}
-        for r in prof:
-            agg[r["stage"]] = agg.get(r["stage"], 0.0) + r["ms"] / args.steps
-        roofline["stages_ms_per_step"] = {k: round(val, 3) for k, val in agg.items()}
+    # roofline: the dominant kernel's own bytes per launch / its mean launch duration (hipEvent pairs on the launch stream); HBM
+    # bytes from the PMC counters (separate rocprofv3 --pmc passes, profiles/pmc_traffic.json) scaled to this run's units per launch
+    roofline = roofline_object(prof, args.steps, value / world, W, H, plan, params["iterations"], traffic_tab) if prof else None
 
     res = "1920x1080" if W == 1920 else f"{W}x{H}"
     if args.config == 3:

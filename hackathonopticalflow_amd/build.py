@@ -18,6 +18,8 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libofarn.so")
 SOURCES = ["kernels_generic.hip", "kernels_fast.hip", "kernels_gauss.hip", "kernels_tile.hip", "kernels_frontend.hip", "kernels_lk.hip", "ofarn_api.hip", "ofarn_api_extras.hip", "ofarn_api_lk.hip", "ofarn_api_stream.hip", "ofarn_api_multi.hip"]
 HEADERS = [os.path.join(CSRC, "ofarn_internal.h"), os.path.join(CSRC, "farneback_device.h"), os.path.join(CSRC, "flow_iter_common.h"), os.path.join(CSRC, "ofarn_host.h"), os.path.join(ROOT, "include", "ofarn.h")]
+# wrong-result / diagnostic experiment bodies, included only under their -D macro (never by the product build)
+HEADERS += sorted(os.path.join(CSRC, "experiments", f) for f in os.listdir(os.path.join(CSRC, "experiments")) if f.endswith(".inc"))
 # -fno-slp-vectorize: the SLP vectoriser turns pairs of f32 operations into v_pk_mul_f32 / v_pk_add_f32,
 # which measured SLOWER than two scalar VALU ops in these VALU-bound kernels (polyexp 2.42 -> 2.00 ms).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -38,18 +40,24 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str |
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     lib = LIB if out is None else os.path.join(HERE, out)
     tag = "" if out is None else "." + os.path.splitext(out)[0]
-    force = force or bool(extra_flags)
+    # a variant build recompiles only the sources that mention one of its -D macros (all of them if a header does, or if a flag
+    # is not a -D); the other objects are the product build's, brought up to date first
+    macros = [f[2:].split("=")[0] for f in extra_flags if f.startswith("-D")]
+    everywhere = len(macros) != len(list(extra_flags)) or any(m in open(h).read() for m in macros for h in HEADERS)
+    if extra_flags and not everywhere:
+        build(force=False, verbose=verbose)
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.rsplit(".", 1)[0] + tag + ".o")
+        variant = bool(extra_flags) and (everywhere or any(m in open(s).read() for m in macros))
+        o = os.path.join(CSRC, src.rsplit(".", 1)[0] + (tag if variant else "") + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + HEADERS + [os.path.abspath(__file__)]):
-            cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", s, "-o", o]
+        if (force and (variant or not extra_flags)) or variant or _stale(o, [s] + HEADERS + [os.path.abspath(__file__)]):
+            cmd = [hipcc] + FLAGS + (list(extra_flags) if variant else []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)
-    if force or _stale(lib, objs):
+    if force or extra_flags or _stale(lib, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", lib] + objs + ["-ldl", "-lpthread"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

@@ -158,10 +158,9 @@ __device__ __forceinline__ void gather_issue(const float *__restrict__ R0, const
     // in one 8-byte load (4-byte aligned: legal for global memory on gfx9+)
     {
         const char *b4 = reinterpret_cast<const char *>(R1);
-#ifdef OFARN_EXP_HALFTAPS   // experiment only (wrong results): what the kernel costs without the two right-hand tap loads
-        const float4 a00 = *reinterpret_cast<const float4 *>(b4 + q * 16u), a01 = a00;
-        const float4 a10 = *reinterpret_cast<const float4 *>(b4 + q10 * 16u), a11 = a10;
-        (void)q01; (void)q11;
+#ifdef OFARN_EXP_HALFTAPS   // wrong-result experiment, kept out of this file: experiments/gather_halftaps.inc
+#define OFARN_EXP_PART 1
+#include "experiments/gather_halftaps.inc"
 #else
         const float4 a00 = *reinterpret_cast<const float4 *>(b4 + q * 16u), a01 = *reinterpret_cast<const float4 *>(b4 + q01 * 16u);
         const float4 a10 = *reinterpret_cast<const float4 *>(b4 + q10 * 16u), a11 = *reinterpret_cast<const float4 *>(b4 + q11 * 16u);
@@ -173,8 +172,8 @@ __device__ __forceinline__ void gather_issue(const float *__restrict__ R0, const
         struct __attribute__((packed, aligned(4))) F2 { float a, b; };
         const char *b1 = reinterpret_cast<const char *>(R1 + 4 * npx);
 #ifdef OFARN_EXP_HALFTAPS
-        const float s0a = *reinterpret_cast<const float *>(b1 + q * 4u), s1a = *reinterpret_cast<const float *>(b1 + q10 * 4u);
-        g.t00[4] = s0a; g.t01[4] = s0a; g.t10[4] = s1a; g.t11[4] = s1a;
+#define OFARN_EXP_PART 2
+#include "experiments/gather_halftaps.inc"
 #else
         const F2 s0 = *reinterpret_cast<const F2 *>(b1 + q * 4u), s1 = *reinterpret_cast<const F2 *>(b1 + q10 * 4u);
         g.t00[4] = s0.a; g.t01[4] = s0.b; g.t10[4] = s1.a; g.t11[4] = s1.b;

@@ -59,18 +59,10 @@ template <> struct FifoVec<15> { typedef ofarn_f16v type; };
 #endif
 constexpr int FI_REGCH = OFARN_FI_REGCH;
 
-// OFARN_STAMPS: diagnostic build that sums s_memtime differences per loop segment (never in the
-// product build; its fences forbid overlaps the real kernel has -- read shares, not lengths).
+// OFARN_STAMPS: diagnostic build with in-kernel s_memtime stamps; its code lives in experiments/flow_iter_stamps.inc
 #ifdef OFARN_STAMPS
-#define STAMP(k)                                                                              \
-    do {                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                    \
-        unsigned long long t_;                                                                \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
-        __builtin_amdgcn_sched_barrier(0);                                                    \
-        seg[k] += t_ - tprev;                                                                 \
-        tprev = t_;                                                                           \
-    } while (0)
+#define OFARN_EXP_PART 1
+#include "experiments/flow_iter_stamps.inc"
 #else
 #define STAMP(k) do { } while (0)
 #endif   // channels whose row FIFO lives in registers
@@ -211,8 +203,8 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
     int buf = 0;
 
 #ifdef OFARN_STAMPS
-    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+#define OFARN_EXP_PART 2
+#include "experiments/flow_iter_stamps.inc"
 #endif
     bool have_prev = false;                  // a row's column sums are in sV[buf ^ 1] awaiting their horizontal pass
     int yprev = 0;
@@ -292,40 +284,13 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
         float m[5], old[5];
         STAMP(7);
 #ifdef OFARN_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // attribute the whole load wait to segment 0
+#define OFARN_EXP_PART 3
+#include "experiments/flow_iter_stamps.inc"
 #endif
         STAMP(0);
-#ifdef OFARN_EXP_SKELETON
-        // Experiment only (wrong results; `python -m hackathonopticalflow_amd.build --out libofarn_skel.so -DOFARN_EXP_SKELETON=1`,
-        // run with OFARN_LIB): the kernel's address stream -- the flow load two rows ahead, the flow-dependent gather of R1 and
-        // the R0 load one row ahead, the float2 store of output row t-(B-1) -- with the arithmetic replaced by a handful of adds
-        // that consume every loaded dword.  =1: no LDS traffic, no barrier; =2: one LDS line written and read per row behind the
-        // same LDS-only barrier.  What it runs at is what the ACCESS PATTERN can be served at; the gap to the real kernel is
-        // latency / overlap.  The output is a constant sub-pixel flow (+ 0 x the sum) so that the next iteration's gathers
-        // stay as displaced and unaligned as with real data.
-        {
-            float acc = 0.f;
-#pragma unroll
-            for (int c = 0; c < 5; c++) acc += (raw.r0[c] + raw.t00[c]) + (raw.t01[c] + raw.t10[c]) + raw.t11[c];
-            acc += raw.fx + raw.fy;
-            float dx, dy;
-            flow_finish(fr, dx, dy);
-            __builtin_amdgcn_sched_barrier(0);
-            flow_issue(row_of(t + 2 - M_), fr);
-            __builtin_amdgcn_sched_barrier(0);
-            gather_issue(R0, R1, npx, w, h, xc, row_of(t + 1 - M_), dx, dy, raw);
-            __builtin_amdgcn_sched_barrier(0);
-            if (step < B - 1) return;
-#if OFARN_EXP_SKELETON == 2
-            sV[step & 1][0][tid] = (double)acc;
-            barrier_lds_only();
-            acc += (float)sV[step & 1][0][tc - M_] + (float)sV[step & 1][0][tc + M_];
-#endif
-            const float z = acc * 1e-30f;
-            if (writer) stg_f2(fout, ((unsigned)(t - (B - 1)) * (unsigned)w + (unsigned)x) * 8u, make_float2(3.25f + z, -5.5f + z));
-            (void)m; (void)old; (void)j;
-            return;
-        }
+#ifdef OFARN_EXP_SKELETON   // wrong-result experiment, kept out of this file: experiments/flow_iter_skeleton.inc
+#define OFARN_EXP_PART 1
+#include "experiments/flow_iter_skeleton.inc"
 #endif
         matrices_finish(raw, bx, ax, h, row_of(t - M_), m);
         STAMP(1);
@@ -400,42 +365,8 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
     };
 
 #if defined(OFARN_EXP_SKELETON) && OFARN_EXP_SKELETON == 3
-    // Skeleton with TWO rows of gathers in flight per thread (flow three rows ahead): is the skeleton's rate set by how many
-    // bytes a wave keeps in flight (then this runs faster than =1) or by what the memory system serves the pattern at (then not)?
-    {
-        GatherRaw rawB;
-        {
-            float dx, dy;
-            flow_finish(frA, dx, dy);
-            __builtin_amdgcn_sched_barrier(0);
-            flow_issue(row_of(y0 - M_ + 2), frA);
-            __builtin_amdgcn_sched_barrier(0);
-            gather_issue(R0, R1, npx, w, h, xc, row_of(y0 - M_ + 1), dx, dy, rawB);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        auto sk_row = [&](const int step, GatherRaw &raw) {
-            const int t = y0 + step;
-            float acc = 0.f;
-#pragma unroll
-            for (int c = 0; c < 5; c++) acc += (raw.r0[c] + raw.t00[c]) + (raw.t01[c] + raw.t10[c]) + raw.t11[c];
-            acc += raw.fx + raw.fy;
-            float dx, dy;
-            flow_finish(frA, dx, dy);
-            __builtin_amdgcn_sched_barrier(0);
-            flow_issue(row_of(t + 3 - M_), frA);
-            __builtin_amdgcn_sched_barrier(0);
-            gather_issue(R0, R1, npx, w, h, xc, row_of(t + 2 - M_), dx, dy, raw);
-            __builtin_amdgcn_sched_barrier(0);
-            if (step < B - 1) return;
-            const float z = acc * 1e-30f;
-            if (writer) stg_f2(fout, ((unsigned)(t - (B - 1)) * (unsigned)w + (unsigned)x) * 8u, make_float2(3.25f + z, -5.5f + z));
-        };
-        for (int step = 0; step < nsteps; step += 2) {
-            sk_row(step, rawA);
-            if (step + 1 < nsteps) sk_row(step + 1, rawB);
-        }
-        return;
-    }
+#define OFARN_EXP_PART 3
+#include "experiments/flow_iter_skeleton.inc"
 #endif
     {
         using K0 = std::integral_constant<int, 0>;
@@ -466,8 +397,8 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
         } else if (have_prev) hsum_row(buf ^ 1, yprev);     // drain the pipeline: last output row
     }
 #ifdef OFARN_STAMPS
-    if (up.dbg && (tid & 63) == 0)
-        for (int k = 0; k < 8; k++) atomicAdd(up.dbg + k, seg[k]);
+#define OFARN_EXP_PART 4
+#include "experiments/flow_iter_stamps.inc"
 #endif
 }
 
@@ -488,17 +419,40 @@ __global__ FI_BOUNDS void k_flow_iter(const float *__restrict__ R, int fstep,
 #define OFARN_PE_OCC
 #define OFARN_PE_WAVES 6
 #endif
+// Output columns per block.  Round 4: 240 ends a block's row segment on a whole 128-byte line in the float4
+// plane (3840 B) but on a HALF line in the scalar plane (960 B = 7.5 lines); 192 ends both on whole lines (3072 + 768 B) and the bare
+// store pattern runs at 5.6 instead of 4.65 TB/s (tools/microbench/hbm_rw.hip, profiles/r04_hbm_rw.txt).  OFARN_PE_ALIGNED: the
+// writers are lanes 0 .. OUTW-1 -- whole waves, each wave's 64 columns starting on a line in both planes -- and the 2N halo columns
+// are handled by the first lanes of the following wave (default: halo lanes first, as in the iteration kernels).
+#ifndef OFARN_PE_OUTW
+#define OFARN_PE_OUTW 0
+#endif
+#ifndef OFARN_PE_ALIGNED
+#define OFARN_PE_ALIGNED 0
+#endif
+#ifndef OFARN_PE_THREADS       // block size of the marching polynomial expansion (experiment: 384 threads / 320 columns, 512 / 480)
+#define OFARN_PE_THREADS FI_THREADS
+#endif
+constexpr int pe_out_width(int n) { return OFARN_PE_OUTW ? OFARN_PE_OUTW : march_out_width(n); }
 template <int N, int SRC>
-__global__ __launch_bounds__(FI_THREADS) OFARN_PE_OCC void k_polyexp_march(const void *__restrict__ src, size_t src_stride,
+__global__ __launch_bounds__(OFARN_PE_THREADS) OFARN_PE_OCC void k_polyexp_march(const void *__restrict__ src, size_t src_stride,
                                                               float *__restrict__ R, int w, int h, int strip_h,
                                                               PolyCoef c, float k0, float k1, float k2, int nt)
 {
     constexpr int TAPS = 2 * N + 1;
-    constexpr int OUTW = march_out_width(N);
-    __shared__ float sRow[2][3][FI_THREADS];
+    constexpr int OUTW = pe_out_width(N);
+    static_assert(OUTW + 2 * N <= OFARN_PE_THREADS, "block too narrow for the output width");
+    __shared__ float sRow[2][3][OFARN_PE_THREADS];
 
     const int tid = threadIdx.x;
-    const int x = blockIdx.x * OUTW - N + tid;
+#if OFARN_PE_ALIGNED
+    // column relative to the block's first output column, and the lane's place in the LDS line (= column + N)
+    const int col = tid < OUTW ? tid : (tid < OUTW + N ? tid - OUTW - N : tid - N);
+    const int li = tid < OUTW ? tid + N : (tid < OUTW + N ? tid - OUTW : tid);
+#else
+    const int col = tid - N, li = tid;
+#endif
+    const int x = blockIdx.x * OUTW + col;
     const int xc = clampi(x, 0, w - 1);
     const int y0 = blockIdx.y * strip_h;
     const int y1 = min(y0 + strip_h, h);
@@ -584,7 +538,7 @@ __global__ __launch_bounds__(FI_THREADS) OFARN_PE_OCC void k_polyexp_march(const
     }
 
     int buf = 0;
-    const bool writer = tid >= N && tid < N + OUTW && x < w;
+    const bool writer = col >= 0 && col < OUTW && x < w;
     float pv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};     // the previous row's result, stored one turn late (see below)
     issue_next(clampi(y0 + N, 0, h - 1));
     for (int y = y0; y < y1; y++) {
@@ -609,12 +563,12 @@ __global__ __launch_bounds__(FI_THREADS) OFARN_PE_OCC void k_polyexp_march(const
             r1 = r1 + c.xg[k] * (b - a);
             r2 = r2 + c.xxg[k] * pp;
         }
-        sRow[buf][0][tid] = r0;
-        sRow[buf][1][tid] = r1;
-        sRow[buf][2][tid] = r2;
+        sRow[buf][0][li] = r0;
+        sRow[buf][1][li] = r1;
+        sRow[buf][2][li] = r2;
         barrier_lds_only();   // __syncthreads() would also drain vmcnt
         if (writer) {
-            const float *p0 = &sRow[buf][0][tid], *p1 = &sRow[buf][1][tid], *p2 = &sRow[buf][2][tid];
+            const float *p0 = &sRow[buf][0][li], *p1 = &sRow[buf][1][li], *p2 = &sRow[buf][2][li];
             const float g0 = c.g[0];
             double b1 = p0[0] * g0, b2 = 0, b3 = p1[0] * g0, b4 = 0, b5 = p2[0] * g0, b6 = 0;
 #pragma unroll
@@ -1128,21 +1082,8 @@ static void launch_flow_iter_m(hipStream_t s, const float *R, int fstep, const f
     (void)d_yofs; (void)d_ya;     // the row table is recomputed in the kernel (resize_coord)
     UpsampleArgs up{reinterpret_cast<const float2 *>(coarse), cw, ch, d_xofs, d_xa, yscale, mul, nullptr};
 #ifdef OFARN_STAMPS
-    static unsigned long long *dbg = nullptr;
-    static int calls = 0;
-    if (!dbg) { (void)hipMalloc((void **)&dbg, 64); (void)hipMemset(dbg, 0, 64); }
-    up.dbg = dbg;
-    if (++calls % 9 == 0 && w >= 1920) {
-        unsigned long long hbuf[8];
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(hbuf, dbg, 64, hipMemcpyDeviceToHost);
-        double tot = 0;
-        for (int k = 0; k < 8; k++) tot += (double)hbuf[k];
-        fprintf(stderr, "[stamps] wait-loads %.1f%% matrices %.1f%% issue %.1f%% hsum(prev row) %.1f%% colsum+ldsw %.1f%% barrier %.1f%% loop-ovh %.1f%%\n",
-                100 * hbuf[0] / tot, 100 * hbuf[1] / tot, 100 * hbuf[2] / tot, 100 * hbuf[5] / tot, 100 * hbuf[3] / tot,
-                100 * hbuf[4] / tot, 100 * hbuf[7] / tot);
-        (void)hipMemset(dbg, 0, 64);
-    }
+#define OFARN_EXP_PART 5
+#include "experiments/flow_iter_stamps.inc"
 #endif
     const float2 *fin = reinterpret_cast<const float2 *>(flow_in);
     float2 *fout = reinterpret_cast<float2 *>(flow_out);
@@ -1216,15 +1157,15 @@ template <int N>
 static void launch_polyexp_march_n(hipStream_t s, const void *src, size_t src_stride, int src_is_u8, float *R, int w, int h,
                                    int nframes, const PolyCoef &c, const float *blur3)
 {
-    constexpr int OUTW = march_out_width(N);
-    const int strip_h = best_strip_units(h, 1, 2 * N, (int)cdivu(w, OUTW) * nframes, OFARN_PE_WAVES);
+    constexpr int OUTW = pe_out_width(N);
+    const int strip_h = best_strip_units(h, 1, 2 * N, (int)cdivu(w, OUTW) * nframes, OFARN_PE_WAVES * FI_THREADS / OFARN_PE_THREADS);
     dim3 grid(cdivu(w, OUTW), cdivu(h, strip_h), nframes);
     const int nt = nt_hint((size_t)nframes * w * h * 20);
     if (src_is_u8)
-        hipLaunchKernelGGL((k_polyexp_march<N, 1>), grid, dim3(FI_THREADS), 0, s, src, src_stride, R, w, h, strip_h, c,
+        hipLaunchKernelGGL((k_polyexp_march<N, 1>), grid, dim3(OFARN_PE_THREADS), 0, s, src, src_stride, R, w, h, strip_h, c,
                            blur3[0], blur3[1], blur3[2], nt);
     else
-        hipLaunchKernelGGL((k_polyexp_march<N, 0>), grid, dim3(FI_THREADS), 0, s, src, src_stride, R, w, h, strip_h, c,
+        hipLaunchKernelGGL((k_polyexp_march<N, 0>), grid, dim3(OFARN_PE_THREADS), 0, s, src, src_stride, R, w, h, strip_h, c,
                            0.f, 0.f, 0.f, nt);
 }
 

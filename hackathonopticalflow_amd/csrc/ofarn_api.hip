@@ -15,6 +15,8 @@ using namespace ofarn_host;
 namespace ofarn_host {
 
 thread_local std::string g_err;
+int g_fake_current_device = -1;
+thread_local int t_last_restored_device = -1, t_device_scopes = 0;
 
 int fail(int code, const char *fmt, ...)
 {
@@ -717,7 +719,7 @@ int ofarn_create(const ofarn_params *params, int device, int max_w, int max_h, i
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(OFARN_E_HIP, "no HIP device visible; libofarn has no CPU path");
     if (device < 0 || device >= ndev) return fail(OFARN_E_INVALID, "device %d out of range [0, %d)", device, ndev);
-    HIP_TRY(hipSetDevice(device));
+    OFARN_ON_DEVICE(device);
     ofarn_ctx *c = new ofarn_ctx();
     c->prm = *params;
     c->device = device;
@@ -777,7 +779,7 @@ int ofarn_create(const ofarn_params *params, int device, int max_w, int max_h, i
 void ofarn_destroy(ofarn_ctx *c)
 {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceScope on_device(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_plan(c);
     for (auto &ws : c->ws)
@@ -796,7 +798,9 @@ void ofarn_destroy(ofarn_ctx *c)
         for (int i = 0; i < 2; i++) {
             if (st.ev_uploaded[i]) (void)hipEventDestroy(st.ev_uploaded[i]);
             if (st.h_stage[i]) (void)hipHostFree(st.h_stage[i]);
+            if (st.h_keep[i]) (void)hipHostFree(st.h_keep[i]);
         }
+        if (st.ev_src_uploaded) (void)hipEventDestroy(st.ev_src_uploaded);
     }
     if (c->stream_state.R) (void)hipFree(c->stream_state.R);
     for (uint8_t *p : {c->stream_state.d_frame, c->stream_state.d_bgr, c->stream_state.d_view, c->stream_state.d_lamps}) if (p) (void)hipFree(p);
@@ -842,7 +846,7 @@ int ofarn_reserve(ofarn_ctx *c, int w, int h, int n_pairs, int pairs_mode)
     if (n_pairs < 1) return fail(OFARN_E_INVALID, "n_pairs must be >= 1");
     if (pairs_mode != OFARN_PAIRS_INDEPENDENT && pairs_mode != OFARN_PAIRS_CONSECUTIVE)
         return fail(OFARN_E_INVALID, "pairs_mode must be 0 or 1");
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     if ((rc = make_plan(c, w, h))) return rc;
     const int np = n_pairs < c->max_batch ? n_pairs : c->max_batch;          // a wave never holds more
     const int nframes = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? np + 1 : 2 * np;
@@ -879,7 +883,7 @@ int ofarn_profile_enable(ofarn_ctx *c, int on)
 int ofarn_profile_read(ofarn_ctx *c, int cap, int *stage, int *level, int *launches, double *ms, double *units)
 {
     if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     for (auto &r : c->prof_pending) {
         HIP_TRY(hipEventSynchronize(r.b));
         float t = 0;
@@ -975,7 +979,7 @@ int calc_batch_device_impl(ofarn_ctx *c, const uint8_t *d_frames, bool bgr, int 
     if (n_pairs == 0) return OFARN_OK;
     const bool use_init = (c->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW) != 0;
     if (use_init && !d_flow) return fail(OFARN_E_INVALID, "OPTFLOW_USE_INITIAL_FLOW needs the flow buffer (it holds the initial flow)");
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     hipStream_t s = pick_stream(c, hip_stream);
     // Recorded into a HIP graph?  Then nothing below may allocate, free or copy synchronously: refuse BEFORE the first such
     // call (it would invalidate the caller's capture) whatever a warm-up call or ofarn_reserve would have prepared.
@@ -1066,7 +1070,7 @@ int ofarn_calc_batch(ofarn_ctx *c, const uint8_t *h_frames, int n_frames, int w,
     if (n_pairs == 0) return OFARN_OK;
     const bool use_init = (c->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW) != 0;
     if (use_init && !h_flow) return fail(OFARN_E_INVALID, "OPTFLOW_USE_INITIAL_FLOW needs the flow buffer (it holds the initial flow)");
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     if ((rc = make_plan(c, w, h))) return rc;
     const size_t fsz = (size_t)w * h;
     const int fstep = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? 1 : 2;
@@ -1112,7 +1116,7 @@ int ofarn_calc(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next, int w
     if (rc) return rc;
     if (!h_prev || !h_next || !h_flow) return fail(OFARN_E_INVALID, "prev, next and flow must not be NULL");
     if (stride < w) return fail(OFARN_E_INVALID, "stride %d < width %d", stride, w);
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     if ((rc = make_plan(c, w, h))) return rc;
     const size_t fsz = (size_t)w * h;
     if ((rc = ensure_staging(c, 2 * fsz, fsz * 2 * sizeof(float), 0))) return rc;
@@ -1128,13 +1132,10 @@ int ofarn_calc(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next, int w
     float *d_out = c->st_flow;
     bool direct = false;
     if (!use_init && c->stream_zero_copy) {
-        hipPointerAttribute_t at;
-        void *dp = nullptr;
-        if (hipPointerGetAttributes(&at, h_flow) == hipSuccess && at.type == hipMemoryTypeHost &&
-            hipHostGetDevicePointer(&dp, h_flow, 0) == hipSuccess && dp) {
+        if (void *dp = mapped_host_range(h_flow, fsz * 2 * sizeof(float))) {
             d_out = static_cast<float *>(dp);
             direct = true;
-        } else (void)hipGetLastError();
+        }
     }
     if ((rc = run_wave(c, c->stream, c->st_frames, 1, OFARN_PAIRS_INDEPENDENT, w, h, d_out, nullptr, nullptr, 0,
                        use_init ? c->st_flow : nullptr))) {
@@ -1158,7 +1159,7 @@ int ofarn_grid_filter_device(ofarn_ctx *c, const float *d_flow, int n, int w, in
     if (!d_flow || !d_mask || !d_v) return fail(OFARN_E_INVALID, "flow, mask and v must not be NULL");
     if (n < 0) return fail(OFARN_E_INVALID, "n < 0");
     if (n == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     if ((rc = make_plan(c, w, h))) return rc;
     if (c->P == 0) return OFARN_OK;
     hipStream_t s = pick_stream(c, hip_stream);
@@ -1175,7 +1176,7 @@ int ofarn_grid_filter(ofarn_ctx *c, const float *h_flow, int n, int w, int h, ui
     if (!h_flow || !h_mask || !h_v) return fail(OFARN_E_INVALID, "flow, mask and v must not be NULL");
     if (n < 0) return fail(OFARN_E_INVALID, "n < 0");
     if (n == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     if ((rc = make_plan(c, w, h))) return rc;
     if (c->P == 0) return OFARN_OK;
     const size_t fsz = (size_t)w * h * 2 * sizeof(float);

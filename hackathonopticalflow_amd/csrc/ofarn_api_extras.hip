@@ -65,7 +65,7 @@ int ofarn_bgr2gray_device(ofarn_ctx *c, const uint8_t *d_bgr, int n, int w, int 
     if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
     if (!d_bgr || !d_gray) return fail(OFARN_E_INVALID, "bgr and gray must not be NULL");
     if (n < 0 || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad size n=%d %dx%d", n, w, h);
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     hipStream_t s = pick_stream(c, hip_stream);
     launch_bgr2gray(s, d_bgr, d_gray, (size_t)n * w * h, kGrayB, kGrayG, kGrayR, kGrayShift);
     HIP_TRY(hipGetLastError());
@@ -79,7 +79,7 @@ int ofarn_bgr2gray(ofarn_ctx *c, const uint8_t *h_bgr, int n, int w, int h, int 
     if (n < 0 || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad size n=%d %dx%d", n, w, h);
     if (stride < 3 * w) return fail(OFARN_E_INVALID, "stride %d < 3 * width %d", stride, w);
     if (n == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     const size_t npx = (size_t)w * h;
     DevTmp in, out;
     int rc;
@@ -99,7 +99,7 @@ int ofarn_flow_hsv_device(ofarn_ctx *c, const float *d_flow, int n, int w, int h
     if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
     if (!d_flow || (!d_hsv && !d_bgr)) return fail(OFARN_E_INVALID, "flow and at least one of hsv, bgr must not be NULL");
     if (n < 0 || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad size n=%d %dx%d", n, w, h);
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     hipStream_t s = pick_stream(c, hip_stream);
     launch_flow_hsv(s, d_flow, (size_t)n * w * h, d_hsv, d_bgr);
     HIP_TRY(hipGetLastError());
@@ -112,7 +112,7 @@ int ofarn_flow_hsv(ofarn_ctx *c, const float *h_flow, int n, int w, int h, uint8
     if (!h_flow || (!h_hsv && !h_bgr)) return fail(OFARN_E_INVALID, "flow and at least one of hsv, bgr must not be NULL");
     if (n < 0 || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad size n=%d %dx%d", n, w, h);
     if (n == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     const size_t npx = (size_t)w * h;
     DevTmp in, o1, o2;
     int rc;
@@ -132,7 +132,7 @@ int ofarn_hsv2bgr(ofarn_ctx *c, const uint8_t *h_hsv, size_t npx, uint8_t *h_bgr
     if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
     if (!h_hsv || !h_bgr) return fail(OFARN_E_INVALID, "hsv and bgr must not be NULL");
     if (npx == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     DevTmp in, out;
     int rc;
     if ((rc = in.alloc(npx * 3)) || (rc = out.alloc(npx * 3))) return rc;
@@ -150,7 +150,7 @@ int ofarn_draw_flow_device(ofarn_ctx *c, const float *d_flow, int n, int w, int 
     if (!d_flow || !d_out) return fail(OFARN_E_INVALID, "flow and out must not be NULL");
     if (n < 0 || w < 1 || h < 1 || step < 1) return fail(OFARN_E_INVALID, "bad arguments n=%d %dx%d step=%d", n, w, h, step);
     if (n == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     double st;
     const int nx = arrow_axis(w, step, &st), ny = arrow_axis(h, step, &st);
     const size_t bytes = (size_t)n * w * h * 3;
@@ -168,7 +168,7 @@ int ofarn_draw_flow(ofarn_ctx *c, const float *h_flow, int n, int w, int h, int 
     if (!h_flow || !h_out) return fail(OFARN_E_INVALID, "flow and out must not be NULL");
     if (n < 0 || w < 1 || h < 1 || step < 1) return fail(OFARN_E_INVALID, "bad arguments n=%d %dx%d step=%d", n, w, h, step);
     if (n == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     double st;
     const int nx = arrow_axis(w, step, &st), ny = arrow_axis(h, step, &st);
     const size_t npx = (size_t)w * h, img = npx * 3;
@@ -190,7 +190,7 @@ int ofarn_add_u8_device(ofarn_ctx *c, const uint8_t *d_a, const uint8_t *d_b, si
 {
     if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
     if (n > 0 && (!d_a || !d_b || !d_out)) return fail(OFARN_E_INVALID, "a, b and out must not be NULL");
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     launch_add_u8(pick_stream(c, hip_stream), d_a, d_b, d_out, n);
     HIP_TRY(hipGetLastError());
     return OFARN_OK;
@@ -201,7 +201,7 @@ int ofarn_add_u8(ofarn_ctx *c, const uint8_t *h_a, const uint8_t *h_b, size_t n,
     if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
     if (n == 0) return OFARN_OK;
     if (!h_a || !h_b || !h_out) return fail(OFARN_E_INVALID, "a, b and out must not be NULL");
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     DevTmp a, b;
     int rc;
     if ((rc = a.alloc(n)) || (rc = b.alloc(n))) return rc;
@@ -224,7 +224,7 @@ int ofarn_draw_lamps_device(ofarn_ctx *c, const uint8_t *d_mask, const uint8_t *
     int rc = lamp_grid(c, w, h, radius, &g, &P);
     if (rc) return rc;
     if (P > 0 && (!d_mask || !d_v)) return fail(OFARN_E_INVALID, "mask and v must not be NULL");
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     launch_draw_lamps(pick_stream(c, hip_stream), d_mask, d_v, P, d_base, d_out, w, h, n, g);
     HIP_TRY(hipGetLastError());
     return OFARN_OK;
@@ -242,7 +242,7 @@ int ofarn_draw_lamps(ofarn_ctx *c, const uint8_t *h_mask, const uint8_t *h_v, in
     if (rc) return rc;
     if (P > 0 && (!h_mask || !h_v)) return fail(OFARN_E_INVALID, "mask and v must not be NULL");
     if (n == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     const size_t img = (size_t)w * h * 3;
     DevTmp dm, base, out;
     if ((rc = dm.alloc((size_t)2 * P + 16)) || (rc = out.alloc(img)) || (h_base && (rc = base.alloc(img)))) return rc;
@@ -275,7 +275,7 @@ int ofarn_flow_arrows_device(ofarn_ctx *c, const float *d_flow, int n, int w, in
     if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
     if (!d_flow || !d_lines) return fail(OFARN_E_INVALID, "flow and lines must not be NULL");
     if (n < 0 || w < 1 || h < 1 || step < 1) return fail(OFARN_E_INVALID, "bad arguments n=%d %dx%d step=%d", n, w, h, step);
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     double st;
     const int nx = arrow_axis(w, step, &st), ny = arrow_axis(h, step, &st);
     hipStream_t s = pick_stream(c, hip_stream);
@@ -290,7 +290,7 @@ int ofarn_flow_arrows(ofarn_ctx *c, const float *h_flow, int n, int w, int h, in
     if (!h_flow || !h_lines) return fail(OFARN_E_INVALID, "flow and lines must not be NULL");
     if (n < 0 || w < 1 || h < 1 || step < 1) return fail(OFARN_E_INVALID, "bad arguments n=%d %dx%d step=%d", n, w, h, step);
     if (n == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     double st;
     const int nx = arrow_axis(w, step, &st), ny = arrow_axis(h, step, &st);
     const size_t npx = (size_t)w * h, K = (size_t)nx * ny;
@@ -312,7 +312,7 @@ int ofarn_stage_resize_area(ofarn_ctx *c, const float *h_flow, int sw, int sh, i
     if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
     if (!h_flow || !h_out) return fail(OFARN_E_INVALID, "NULL argument");
     if (sw < 1 || sh < 1 || dw < 1 || dh < 1) return fail(OFARN_E_INVALID, "bad sizes");
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     const size_t saved = c->plan_allocs.size();
     AreaTabHost t;
     int rc = build_area_tab(c, sw, sh, dw, dh, t);
@@ -336,7 +336,7 @@ int ofarn_stage_pyrdown(ofarn_ctx *c, const uint8_t *h_img, int w, int h, uint8_
 {
     if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
     if (!h_img || !h_out || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad argument");
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     const size_t npx = (size_t)w * h, nout = (size_t)((w + 1) / 2) * ((h + 1) / 2);
     DevTmp in, out;
     int rc;
@@ -352,7 +352,7 @@ int ofarn_stage_scharr(ofarn_ctx *c, const uint8_t *h_img, int w, int h, int16_t
 {
     if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
     if (!h_img || !h_out || w < 1 || h < 1) return fail(OFARN_E_INVALID, "bad argument");
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     const size_t npx = (size_t)w * h;
     DevTmp in, out;
     int rc;
@@ -372,7 +372,7 @@ int ofarn_stage_level_image(ofarn_ctx *c, const uint8_t *h_img, int w, int h, in
     int rc = check_size(c, w, h);
     if (rc) return rc;
     if (!h_img || !h_out) return fail(OFARN_E_INVALID, "NULL argument");
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     if ((rc = make_plan(c, w, h))) return rc;
     if (k < 0 || k >= (int)c->lv.size()) return fail(OFARN_E_INVALID, "level %d out of range", k);
     const Level &L = c->lv[k];
@@ -420,7 +420,7 @@ int ofarn_stage_polyexp(ofarn_ctx *c, const float *h_img, int w, int h, float *h
     int rc = check_size(c, w, h);
     if (rc) return rc;
     if (!h_img || !h_R) return fail(OFARN_E_INVALID, "NULL argument");
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     const size_t npx = (size_t)w * h;
     if ((rc = ws_reserve(c, 0, 0, npx, 0, 0, 0))) return rc;
     if ((rc = begin_call(c, c->stream))) return rc;
@@ -443,7 +443,7 @@ int ofarn_stage_update_matrices(ofarn_ctx *c, const float *h_R0, const float *h_
     int rc = check_size(c, w, h);
     if (rc) return rc;
     if (!h_R0 || !h_R1 || !h_flow || !h_M) return fail(OFARN_E_INVALID, "NULL argument");
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     const size_t npx = (size_t)w * h;
     std::vector<float> d0, d1;
     r_to_device_layout(h_R0, npx, d0);
@@ -467,7 +467,7 @@ int ofarn_stage_blur_solve(ofarn_ctx *c, const float *h_M, int w, int h, float *
     int rc = check_size(c, w, h);
     if (rc) return rc;
     if (!h_M || !h_flow) return fail(OFARN_E_INVALID, "NULL argument");
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     const size_t npx = (size_t)w * h;
     std::vector<float> mp(npx * 5);
     for (size_t o = 0; o < npx; o++)
@@ -490,7 +490,7 @@ int ofarn_stage_flow_upsample(ofarn_ctx *c, const float *h_flow, int sw, int sh,
     if (rc) return rc;
     if ((rc = check_size(c, sw, sh))) return rc;
     if (!h_flow || !h_out) return fail(OFARN_E_INVALID, "NULL argument");
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     std::vector<int> xo, yo;
     std::vector<float> xa, ya;
     resize_tables(sw, dw, xo, xa);

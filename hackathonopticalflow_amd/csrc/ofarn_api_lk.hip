@@ -117,7 +117,7 @@ int ofarn_lk_calc_batch_device(ofarn_ctx *c, const uint8_t *d_frames, int n_fram
     if (n_pairs < 0 || npts < 0 || (pairs_mode == OFARN_PAIRS_INDEPENDENT && (n_frames & 1)))
         return fail(OFARN_E_INVALID, "n_frames=%d does not form whole pairs in mode %d", n_frames, pairs_mode);
     if (n_pairs == 0 || npts == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     hipStream_t s = pick_stream(c, hip_stream);
     if ((rc = begin_call(c, s))) return rc;                       // the LK pyramid workspace is shared between calls
     const size_t fsz = (size_t)w * h;
@@ -147,7 +147,7 @@ int ofarn_lk_calc(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next, in
     if (stride < w) return fail(OFARN_E_INVALID, "stride %d < width %d", stride, w);
     if (npts < 0) return fail(OFARN_E_INVALID, "npts < 0");
     if (npts == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     const size_t fsz = (size_t)w * h;
     if ((rc = ensure_staging(c, 2 * fsz, 0, 0))) return rc;
     DevTmp pts, nxt, st, er;
@@ -177,7 +177,7 @@ int ofarn_vector_filter_device(ofarn_ctx *c, const float *d_vecs, int n, int w, 
     if (!d_vecs || !d_mask || !d_v) return fail(OFARN_E_INVALID, "vectors, mask and v must not be NULL");
     if (n < 0) return fail(OFARN_E_INVALID, "n < 0");
     if (n == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     if ((rc = make_plan(c, w, h))) return rc;
     if (c->P == 0) return OFARN_OK;
     hipStream_t s = pick_stream(c, hip_stream);
@@ -193,7 +193,7 @@ int ofarn_vector_filter(ofarn_ctx *c, const float *h_vecs, int n, int w, int h, 
     if (!h_vecs || !h_mask || !h_v) return fail(OFARN_E_INVALID, "vectors, mask and v must not be NULL");
     if (n < 0) return fail(OFARN_E_INVALID, "n < 0");
     if (n == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     if ((rc = make_plan(c, w, h))) return rc;
     if (c->P == 0) return OFARN_OK;
     const size_t P = (size_t)c->P;
@@ -218,7 +218,7 @@ int ofarn_draw_vectors_device(ofarn_ctx *c, const int32_t *d_iflow, const uint8_
     if (!d_out) return fail(OFARN_E_INVALID, "out is NULL");
     if (n < 0) return fail(OFARN_E_INVALID, "n < 0");
     if (n == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     if ((rc = make_plan(c, w, h))) return rc;
     if (c->P > 0 && (!d_iflow || !d_mask)) return fail(OFARN_E_INVALID, "iflow and mask must not be NULL");
     hipStream_t s = pick_stream(c, hip_stream);
@@ -235,7 +235,7 @@ int ofarn_draw_vectors(ofarn_ctx *c, const int32_t *h_iflow, const uint8_t *h_ma
     if (!h_out) return fail(OFARN_E_INVALID, "out is NULL");
     if (n < 0) return fail(OFARN_E_INVALID, "n < 0");
     if (n == 0) return OFARN_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     if ((rc = make_plan(c, w, h))) return rc;
     const size_t P = (size_t)c->P, img = (size_t)w * h * 3;
     if (P > 0 && (!h_iflow || !h_mask)) return fail(OFARN_E_INVALID, "iflow and mask must not be NULL");

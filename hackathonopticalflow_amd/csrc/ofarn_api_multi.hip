@@ -12,6 +12,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
+#include <memory>
+#include <functional>
 #include <mutex>
 #include <thread>
 
@@ -56,7 +59,22 @@ Rccl &rccl()
 
 }  // namespace
 
+// One persistent host thread per device, created by ofarn_multi_create and joined by ofarn_multi_destroy (round 3 created and
+// joined 2 x G std::threads per call and ran the n = 1 case on the caller's thread, which left the caller's current device
+// changed).  A worker sets its device once; everything that touches a device -- phases 1 and 3 of a batch, the RCCL group (on
+// worker 0), creation, destruction, synchronisation -- runs on workers, so the calling thread's current device is never touched.
+struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, done = false, quit = false;
+    int device = 0;
+    bool device_ok = false;
+};
+
 struct ofarn_multi {
+    std::vector<std::unique_ptr<Worker>> workers;
     int n = 0;
     int max_w = 0, max_h = 0, max_batch = 0;
     ofarn_params prm{};
@@ -101,38 +119,103 @@ void shard(int n_pairs, int rank, int world, int &start, int &count)
     count = base + (rank < rem ? 1 : 0);
 }
 
-// Runs fn(g) on one host thread per device; returns the first failing rank's code and leaves its message for ofarn_last_error().
+// Every index a multi-device batch uses, in one host-only place (ofarn_gather_plan exports it; tests/test_host_abi.py checks it on
+// the CPU against the Python mirror for ragged and even pair counts, 1 ... 8 devices -- the paths a one-GPU box cannot run):
+//   rank r owns pairs [start[r], start[r] + count[r]);
+//   cap = the largest shard: every rank contributes cap rows of P bytes to the all-gather, its own at row r * cap of a padded
+//         array u8[world][cap][P] (send buffer = receive buffer + gather_off[r]: in place);
+//   even = every shard is full, so the padded array IS the global u8[n_pairs][P] array and nothing is compacted;
+//   otherwise rank r's count[r] rows move from gather_off[r] to global_off[r] = start[r] * P of the compact array.
+struct GatherPlan {
+    int world = 0, n_pairs = 0, P = 0, cap = 0;
+    bool even = true;
+    std::vector<int> start, count;
+    std::vector<size_t> gather_off, global_off;
+    size_t padded_bytes() const { return (size_t)world * cap * P; }
+    size_t rank_bytes() const { return (size_t)cap * P; }
+};
+
+GatherPlan gather_plan(int n_pairs, int world, int P)
+{
+    GatherPlan g;
+    g.world = world; g.n_pairs = n_pairs < 0 ? 0 : n_pairs; g.P = P < 0 ? 0 : P;
+    g.start.resize(world); g.count.resize(world); g.gather_off.resize(world); g.global_off.resize(world);
+    for (int r = 0; r < world; r++) { shard(g.n_pairs, r, world, g.start[r], g.count[r]); g.cap = std::max(g.cap, g.count[r]); }
+    g.even = g.n_pairs == g.cap * world;
+    for (int r = 0; r < world; r++) {
+        g.gather_off[r] = (size_t)r * g.cap * g.P;
+        g.global_off[r] = (size_t)g.start[r] * g.P;
+    }
+    return g;
+}
+
+void worker_main(Worker *w)
+{
+    w->device_ok = hipSetDevice(w->device) == hipSuccess;
+    if (!w->device_ok) (void)hipGetLastError();
+    std::unique_lock<std::mutex> lk(w->mu);
+    for (;;) {
+        w->cv.wait(lk, [&] { return w->has_job || w->quit; });
+        if (w->has_job) {
+            std::function<void()> job = std::move(w->job);
+            w->has_job = false;
+            lk.unlock();
+            job();
+            lk.lock();
+            w->done = true;
+            w->cv.notify_all();
+            continue;
+        }
+        if (w->quit) return;
+    }
+}
+
+void post(Worker *w, std::function<void()> job)
+{
+    std::lock_guard<std::mutex> lk(w->mu);
+    w->job = std::move(job);
+    w->has_job = true;
+    w->done = false;
+    w->cv.notify_all();
+}
+
+void wait_done(Worker *w)
+{
+    std::unique_lock<std::mutex> lk(w->mu);
+    w->cv.wait(lk, [&] { return w->done; });
+    w->done = false;
+}
+
+// Runs fn(g) on device g's worker thread for g in [first, last); returns the first failing rank's code and leaves its message for
+// ofarn_last_error() on the calling thread.
 template <typename F>
-int on_all_devices(ofarn_multi *m, F &&fn)
+int on_devices(ofarn_multi *m, int first, int last, F &&fn)
 {
     std::vector<int> rc(m->n, OFARN_OK);
     std::vector<std::string> msg(m->n);
-    auto body = [&](int g) {
-        if (hipSetDevice(m->dev[g]) != hipSuccess) { (void)hipGetLastError(); rc[g] = OFARN_E_HIP; msg[g] = "hipSetDevice failed"; return; }
-        rc[g] = fn(g);
-        if (rc[g]) msg[g] = ofarn_last_error();          // thread-local: carry it over to the calling thread
-    };
-    if (m->n == 1) body(0);
-    else {
-        std::vector<std::thread> th;
-        for (int g = 0; g < m->n; g++) th.emplace_back(body, g);
-        for (auto &t : th) t.join();
-    }
-    for (int g = 0; g < m->n; g++)
+    for (int g = first; g < last; g++)
+        post(m->workers[g].get(), [&, g] {
+            if (!m->workers[g]->device_ok) { rc[g] = OFARN_E_HIP; msg[g] = "hipSetDevice failed"; return; }
+            rc[g] = fn(g);
+            if (rc[g]) msg[g] = ofarn_last_error();          // thread-local: carry it over to the calling thread
+        });
+    for (int g = first; g < last; g++) wait_done(m->workers[g].get());
+    for (int g = first; g < last; g++)
         if (rc[g]) return fail(rc[g], "device %d (rank %d): %s", m->dev[g], g, msg[g].c_str());
     return OFARN_OK;
 }
+template <typename F> int on_all_devices(ofarn_multi *m, F &&fn) { return on_devices(m, 0, m->n, fn); }
 
 // The one collective: after every device has written its shard's maps at rank * cap rows of its own gather buffers, all-gather them
 // in place (send buffer = recv buffer + rank * cap * P), all devices inside one group.
-int gather_maps(ofarn_multi *m, int cap, int P, const std::vector<uint8_t *> &gmask, const std::vector<uint8_t *> &gv)
+int gather_maps(ofarn_multi *m, const GatherPlan &gp, const std::vector<uint8_t *> &gmask, const std::vector<uint8_t *> &gv)
 {
     Rccl &R = rccl();
-    const size_t cnt = (size_t)cap * P;
+    const size_t cnt = gp.rank_bytes();
     ncclResult_t r = R.GroupStart();
     for (int g = 0; g < m->n && r == ncclSuccess; g++) {
-        r = R.AllGather(gmask[g] + (size_t)g * cnt, gmask[g], cnt, ncclUint8, m->comm[g], m->stream[g]);
-        if (r == ncclSuccess) r = R.AllGather(gv[g] + (size_t)g * cnt, gv[g], cnt, ncclUint8, m->comm[g], m->stream[g]);
+        r = R.AllGather(gmask[g] + gp.gather_off[g], gmask[g], cnt, ncclUint8, m->comm[g], m->stream[g]);
+        if (r == ncclSuccess) r = R.AllGather(gv[g] + gp.gather_off[g], gv[g], cnt, ncclUint8, m->comm[g], m->stream[g]);
         m->gathers += 2;
     }
     const ncclResult_t e = R.GroupEnd();
@@ -170,10 +253,9 @@ int multi_calc(ofarn_multi *m, const uint8_t *h_frames, const uint8_t *const *d_
     if (P < 0) return P;
     const size_t fsz = (size_t)w * h;
     const int fstep = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? 1 : 2;
-    std::vector<int> start(G), count(G);
-    int cap = 0;
-    for (int g = 0; g < G; g++) { shard(n_pairs, g, G, start[g], count[g]); cap = std::max(cap, count[g]); }
-    const bool even = n_pairs == cap * G;      // every shard full: the gather buffer IS the global array
+    const GatherPlan gp = gather_plan(n_pairs, G, P);
+    const std::vector<int> &start = gp.start, &count = gp.count;
+    const bool even = gp.even;                 // every shard full: the gather buffer IS the global array
     const bool gather = want_maps && P > 0;
     const bool use_init = (m->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW) != 0;
     std::vector<uint8_t *> gmask(G, nullptr), gv(G, nullptr);
@@ -184,7 +266,7 @@ int multi_calc(ofarn_multi *m, const uint8_t *h_frames, const uint8_t *const *d_
         ofarn_multi::Buf &b = m->buf[g];
         int r;
         if (gather) {
-            const size_t gbytes = (size_t)G * cap * P;
+            const size_t gbytes = gp.padded_bytes();
             uint8_t *user_m = host ? nullptr : d_mask_all[g], *user_v = host ? nullptr : d_v_all[g];
             if (even && user_m) { gmask[g] = user_m; gv[g] = user_v; }           // gather straight into the caller's arrays
             else {
@@ -214,14 +296,14 @@ int multi_calc(ofarn_multi *m, const uint8_t *h_frames, const uint8_t *const *d_
             HIP_TRY(hipEventRecord(ev0, m->stream[0]));
         }
         if (np) {
-            uint8_t *mk = gather ? gmask[g] + (size_t)g * cap * P : nullptr, *vv = gather ? gv[g] + (size_t)g * cap * P : nullptr;
+            uint8_t *mk = gather ? gmask[g] + gp.gather_off[g] : nullptr, *vv = gather ? gv[g] + gp.gather_off[g] : nullptr;
             if ((r = ofarn_calc_batch_device(m->ctx[g], frames_g, nf, w, h, pairs_mode, flow_g, mk, vv, m->stream[g]))) return r;
         }
         return OFARN_OK;
     });
 
-    // phase 2, calling thread: the one collective, all devices in one RCCL group
-    if (!rc && gather) rc = gather_maps(m, cap, P, gmask, gv);
+    // phase 2, worker 0: the one collective, all devices in one RCCL group
+    if (!rc && gather) rc = on_devices(m, 0, 1, [&](int) -> int { return gather_maps(m, gp, gmask, gv); });
 
     // phase 3, one host thread per device again: compaction of ragged shards, copies back to the host, synchronisation
     const int rc3 = on_all_devices(m, [&](int g) -> int {
@@ -239,8 +321,8 @@ int multi_calc(ofarn_multi *m, const uint8_t *h_frames, const uint8_t *const *d_
             if (out_m && out_m != gmask[g])
                 for (int r = 0; r < G; r++) {
                     if (!count[r]) continue;
-                    HIP_TRY(hipMemcpyAsync(out_m + (size_t)start[r] * P, gmask[g] + (size_t)r * cap * P, (size_t)count[r] * P, hipMemcpyDeviceToDevice, m->stream[g]));
-                    HIP_TRY(hipMemcpyAsync(out_v + (size_t)start[r] * P, gv[g] + (size_t)r * cap * P, (size_t)count[r] * P, hipMemcpyDeviceToDevice, m->stream[g]));
+                    HIP_TRY(hipMemcpyAsync(out_m + gp.global_off[r], gmask[g] + gp.gather_off[r], (size_t)count[r] * P, hipMemcpyDeviceToDevice, m->stream[g]));
+                    HIP_TRY(hipMemcpyAsync(out_v + gp.global_off[r], gv[g] + gp.gather_off[r], (size_t)count[r] * P, hipMemcpyDeviceToDevice, m->stream[g]));
                 }
             if (host && g == 0) {
                 const uint8_t *sm = even ? gmask[0] : b.mask_all, *sv = even ? gv[0] : b.v_all;
@@ -254,15 +336,16 @@ int multi_calc(ofarn_multi *m, const uint8_t *h_frames, const uint8_t *const *d_
         // the host variant is synchronous; the device variant returns with everything enqueued on the devices' streams -- and
         // synchronises too when an earlier phase failed, so that nothing is left running on buffers the caller may free
         if (host || rc) HIP_TRY(hipStreamSynchronize(m->stream[g]));
+        if (g == 0) {
+            if (ev0 && ev1 && host && !rc) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) m->last_ms = ms; else (void)hipGetLastError();
+            }
+            if (ev0) (void)hipEventDestroy(ev0);
+            if (ev1) (void)hipEventDestroy(ev1);
+        }
         return OFARN_OK;
     });
-    if (ev0 && ev1 && host && !rc && !rc3) {
-        (void)hipSetDevice(m->dev[0]);
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) m->last_ms = ms; else (void)hipGetLastError();
-    }
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
     return rc ? rc : rc3;
 }
 
@@ -278,6 +361,22 @@ int ofarn_shard_pairs(int n_pairs, int rank, int world, int *start, int *count)
     shard(n_pairs, rank, world, s, c);
     if (start) *start = s;
     if (count) *count = c;
+    return OFARN_OK;
+}
+
+int ofarn_gather_plan(int n_pairs, int world, int P, int *start, int *count, int *cap, int *even, uint64_t *gather_off,
+                      uint64_t *global_off)
+{
+    if (world < 1 || n_pairs < 0 || P < 0) return fail(OFARN_E_INVALID, "bad n_pairs/world/P %d/%d/%d", n_pairs, world, P);
+    const GatherPlan g = gather_plan(n_pairs, world, P);
+    for (int r = 0; r < world; r++) {
+        if (start) start[r] = g.start[r];
+        if (count) count[r] = g.count[r];
+        if (gather_off) gather_off[r] = g.gather_off[r];
+        if (global_off) global_off[r] = g.global_off[r];
+    }
+    if (cap) *cap = g.cap;
+    if (even) *even = g.even ? 1 : 0;
     return OFARN_OK;
 }
 
@@ -307,17 +406,25 @@ int ofarn_multi_create(const ofarn_params *params, const int *devices, int n_dev
     m->ctx.assign(n_devices, nullptr);
     m->stream.assign(n_devices, nullptr);
     m->buf.resize(n_devices);
-    int rc = OFARN_OK;
-    for (int g = 0; g < n_devices && !rc; g++) {
-        rc = ofarn_create(params, dev[g], max_w, max_h, max_batch_per_device, &m->ctx[g]);
-        if (!rc && (hipSetDevice(dev[g]) != hipSuccess || hipStreamCreateWithFlags(&m->stream[g], hipStreamNonBlocking) != hipSuccess))
-            rc = fail(OFARN_E_HIP, "stream creation on device %d failed", dev[g]);
+    for (int g = 0; g < n_devices; g++) {
+        m->workers.emplace_back(new Worker());
+        m->workers[g]->device = dev[g];
+        m->workers[g]->th = std::thread(worker_main, m->workers[g].get());
     }
-    if (!rc) {
-        m->comm.assign(n_devices, nullptr);
-        const ncclResult_t r = R.CommInitAll(m->comm.data(), n_devices, dev.data());
-        if (r != ncclSuccess) { m->comm.clear(); rc = fail(OFARN_E_HIP, "ncclCommInitAll over %d device(s) failed: %s", n_devices, R.GetErrorString(r)); }
-    }
+    int rc = on_all_devices(m, [&](int g) -> int {
+        int r = ofarn_create(params, dev[g], max_w, max_h, max_batch_per_device, &m->ctx[g]);
+        if (!r && hipStreamCreateWithFlags(&m->stream[g], hipStreamNonBlocking) != hipSuccess)
+            r = fail(OFARN_E_HIP, "stream creation on device %d failed", dev[g]);
+        return r;
+    });
+    if (!rc)
+        rc = on_devices(m, 0, 1, [&](int) -> int {
+            m->comm.assign(n_devices, nullptr);
+            const ncclResult_t r = R.CommInitAll(m->comm.data(), n_devices, dev.data());
+            if (r != ncclSuccess) { m->comm.clear(); return fail(OFARN_E_HIP, "ncclCommInitAll over %d device(s) failed: %s", n_devices, R.GetErrorString(r)); }
+            (void)hipSetDevice(dev[0]);          // ncclCommInitAll visits every device; worker 0 stays on its own
+            return OFARN_OK;
+        });
     if (rc) { const std::string keep = ofarn_last_error(); ofarn_multi_destroy(m); return fail(rc, "%s", keep.c_str()); }
     *out = m;
     return OFARN_OK;
@@ -326,17 +433,24 @@ int ofarn_multi_create(const ofarn_params *params, const int *devices, int n_dev
 void ofarn_multi_destroy(ofarn_multi *m)
 {
     if (!m) return;
-    for (int g = 0; g < m->n; g++) {
-        (void)hipSetDevice(m->dev[g]);
-        if (m->stream[g]) (void)hipStreamSynchronize(m->stream[g]);
+    if ((int)m->workers.size() == m->n && m->n > 0) {
+        (void)on_all_devices(m, [&](int g) -> int { if (m->stream[g]) (void)hipStreamSynchronize(m->stream[g]); return OFARN_OK; });
+        (void)on_devices(m, 0, 1, [&](int) -> int {
+            for (ncclComm_t c : m->comm) if (c) (void)rccl().CommDestroy(c);
+            (void)hipSetDevice(m->dev[0]);
+            return OFARN_OK;
+        });
+        (void)on_all_devices(m, [&](int g) -> int {
+            ofarn_multi::Buf &b = m->buf[g];
+            for (void *p : {(void *)b.frames, (void *)b.flow, (void *)b.gmask, (void *)b.gv, (void *)b.mask_all, (void *)b.v_all}) if (p) (void)hipFree(p);
+            if (m->stream[g]) (void)hipStreamDestroy(m->stream[g]);
+            if (m->ctx[g]) ofarn_destroy(m->ctx[g]);
+            return OFARN_OK;
+        });
     }
-    for (ncclComm_t c : m->comm) if (c) (void)rccl().CommDestroy(c);
-    for (int g = 0; g < m->n; g++) {
-        (void)hipSetDevice(m->dev[g]);
-        ofarn_multi::Buf &b = m->buf[g];
-        for (void *p : {(void *)b.frames, (void *)b.flow, (void *)b.gmask, (void *)b.gv, (void *)b.mask_all, (void *)b.v_all}) if (p) (void)hipFree(p);
-        if (m->stream[g]) (void)hipStreamDestroy(m->stream[g]);
-        if (m->ctx[g]) ofarn_destroy(m->ctx[g]);
+    for (auto &w : m->workers) {
+        { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; w->cv.notify_all(); }
+        if (w->th.joinable()) w->th.join();
     }
     delete m;
 }
@@ -371,11 +485,7 @@ int ofarn_multi_calc_batch_device(ofarn_multi *m, const uint8_t *const *d_frames
 int ofarn_multi_synchronize(ofarn_multi *m)
 {
     if (!m) return fail(OFARN_E_INVALID, "multi is NULL");
-    for (int g = 0; g < m->n; g++) {
-        HIP_TRY(hipSetDevice(m->dev[g]));
-        HIP_TRY(hipStreamSynchronize(m->stream[g]));
-    }
-    return OFARN_OK;
+    return on_all_devices(m, [&](int g) -> int { HIP_TRY(hipStreamSynchronize(m->stream[g])); return OFARN_OK; });
 }
 
 #pragma GCC visibility pop

@@ -6,8 +6,55 @@
 // Results are those of ofarn_calc on (previous frame, new frame), bit for bit.
 #include "ofarn_host.h"
 
+#include <map>
+#include <mutex>
+
 using namespace ofarn;
 using namespace ofarn_host;
+
+namespace ofarn_host {
+
+// Blocks handed out by ofarn_host_alloc: base address -> size.  A pointer into one of them is checked against the block's extent
+// here; page-locked memory from elsewhere (hipHostMalloc, hipHostRegister, a torch pin_memory() tensor) is looked up in the runtime.
+static std::mutex g_pins_mu;
+static std::map<uintptr_t, size_t> g_pins;
+
+// "The GPU may write [p, p + bytes) through the returned pointer" -- or nullptr.  Round 3 asked only whether p was page-locked: a
+// pointer into the tail of a smaller page-locked block passed and became an out-of-bounds device write.
+void *mapped_host_range(const void *p, size_t bytes)
+{
+    if (!p) return nullptr;
+    const uintptr_t a = (uintptr_t)p;
+    bool known = false, covered = false;
+    {
+        std::lock_guard<std::mutex> lk(g_pins_mu);
+        auto it = g_pins.upper_bound(a);
+        if (it != g_pins.begin()) {
+            --it;
+            if (a < it->first + it->second) { known = true; covered = bytes <= it->second && a - it->first <= it->second - bytes; }
+        }
+    }
+    if (known && !covered) return nullptr;
+    hipPointerAttribute_t at;
+    void *dp = nullptr;
+    if (!(hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost &&
+          hipHostGetDevicePointer(&dp, const_cast<void *>(p), 0) == hipSuccess && dp)) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (known) return dp;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)dp) != hipSuccess || !base) {
+        (void)hipGetLastError();
+        return nullptr;                        // extent unknown: the copy path is always right
+    }
+    const uintptr_t b = (uintptr_t)base, d = (uintptr_t)dp;
+    if (d < b || bytes > size || d - b > size - bytes) return nullptr;
+    return dp;
+}
+
+}  // namespace ofarn_host
 
 namespace {
 
@@ -80,7 +127,7 @@ int stream_check(ofarn_ctx *c, int w, int h, hipStream_t s = nullptr, bool devic
 {
     int rc = check_size(c, w, h);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipSetDevice(c->device));        // the entry point's OFARN_ON_DEVICE scope restores the caller's device
     const ofarn_ctx::Stream &st = c->stream_state;
     if (device_entry && stream_is_capturing(s) && (c->plan_w != w || c->plan_h != h || st.w != w || st.h != h || !st.R))
         return fail(OFARN_E_INVALID, "the stream is being captured and this context's streaming session has not seen %dx%d frames yet: "
@@ -113,6 +160,7 @@ int ofarn_stream_next_device(ofarn_ctx *c, const uint8_t *d_gray, int w, int h, 
                              void *hip_stream)
 {
     if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    OFARN_ON_DEVICE(c->device);
     int rc = stream_check(c, w, h, pick_stream(c, hip_stream), true);
     if (rc) return rc;
     if (!d_gray) return fail(OFARN_E_INVALID, "frame is NULL");
@@ -131,6 +179,7 @@ int ofarn_stream_next_device_bgr(ofarn_ctx *c, const uint8_t *d_bgr, int w, int 
                                  void *hip_stream)
 {
     if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    OFARN_ON_DEVICE(c->device);
     int rc = stream_check(c, w, h, pick_stream(c, hip_stream), true);
     if (rc) return rc;
     if (!d_bgr) return fail(OFARN_E_INVALID, "frame is NULL");
@@ -150,6 +199,8 @@ int ofarn_stream_next_device_bgr(ofarn_ctx *c, const uint8_t *d_bgr, int w, int 
 static int stream_next_host(ofarn_ctx *c, const uint8_t *h_frame, int bgr, int w, int h, int stride, float *h_flow,
                             uint8_t *h_mask, uint8_t *h_v)
 {
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    OFARN_ON_DEVICE(c->device);
     int rc = stream_check(c, w, h);
     if (rc) return rc;
     const int bpp = bgr ? 3 : 1;
@@ -177,13 +228,10 @@ static int stream_next_host(ofarn_ctx *c, const uint8_t *h_frame, int bgr, int w
     float *d_out = c->st_flow;
     bool direct = false;
     if (had && !use_init && c->stream_zero_copy) {
-        hipPointerAttribute_t at;
-        void *dp = nullptr;
-        if (hipPointerGetAttributes(&at, h_flow) == hipSuccess && at.type == hipMemoryTypeHost &&
-            hipHostGetDevicePointer(&dp, h_flow, 0) == hipSuccess && dp) {
+        if (void *dp = mapped_host_range(h_flow, fsz * 2 * sizeof(float))) {
             d_out = static_cast<float *>(dp);
             direct = true;
-        } else (void)hipGetLastError();
+        }
     }
     const int turn = stream_turn(c, s, st.d_frame, w, h, d_out, h_mask ? c->st_mask : nullptr, h_mask ? c->st_v : nullptr);
     if (turn < 0) { (void)end_call(c, s); return turn; }
@@ -219,6 +267,136 @@ int ofarn_stream_next_danger(ofarn_ctx *c, const uint8_t *h_gray, int w, int h, 
     return stream_next_host(c, h_gray, 0, w, h, stride, h_flow, h_mask, h_v);
 }
 
+// ofarn_calc for a caller that hands over consecutive pairs (DenseOF.py:519-525: flow = calculate_optical_flow(prev_gray, gray);
+// prev_gray = gray), with ofarn_calc's contract: the result is a function of (prev, next) alone, for EVERY input.  The context
+// keeps, page-locked on the host, a byte copy of the frame it was last given as `next` (the copy doubles as the upload's staging
+// buffer, which a pageable source needs anyway).  When `prev` equals that copy -- all w x h bytes compared, no fingerprint -- the
+// frame already on the device with its level images and polynomial expansions is reused and only `next` is uploaded and
+// expanded; otherwise both frames are.  The comparison runs on the host WHILE the device already computes the turn it would allow
+// (the optimistic turn is simply redone from both frames if the comparison fails), so exactness costs no latency in the loop.
+// With OPTFLOW_USE_INITIAL_FLOW (h_flow is in/out) the comparison comes first.  *reused (optional): 1 if the frame was reused.
+int ofarn_calc_reuse(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next, int w, int h, int stride_prev, int stride_next,
+                     float *h_flow, int *reused)
+{
+    if (reused) *reused = 0;
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    OFARN_ON_DEVICE(c->device);
+    int rc = stream_check(c, w, h);
+    if (rc) return rc;
+    if (!h_prev || !h_next || !h_flow) return fail(OFARN_E_INVALID, "prev, next and flow must not be NULL");
+    if (stride_prev < w || stride_next < w) return fail(OFARN_E_INVALID, "stride %d / %d < width %d", stride_prev, stride_next, w);
+    ofarn_ctx::Stream &st = c->stream_state;
+    const size_t fsz = (size_t)w * h, flow_bytes = fsz * 2 * sizeof(float);
+    if ((rc = grow_u8(c, &st.d_frame, &st.frame_cap, fsz, "streaming frame buffer"))) return rc;
+    if ((rc = ensure_staging(c, 0, flow_bytes, 0))) return rc;
+    hipStream_t s = c->stream;
+    if (fsz > st.keep_cap) {
+        for (int i = 0; i < 2; i++)
+            if (st.h_keep[i]) { (void)hipHostFree(st.h_keep[i]); st.h_keep[i] = nullptr; }
+        st.keep_cap = 0;
+        st.keep_valid = false;
+        for (int i = 0; i < 2; i++)
+            if (hipHostMalloc((void **)&st.h_keep[i], fsz, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                st.h_keep[i] = nullptr;
+                return fail(OFARN_E_NOMEM, "page-locked frame copies of %zu bytes could not be allocated", fsz);
+            }
+        st.keep_cap = fsz;
+    }
+    if ((rc = begin_call(c, s))) return rc;
+    const bool use_init = (c->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW) != 0;
+    // h_keep[keep_cur] is the frame in the session's current slot only if no other entry point has moved the session since
+    bool cand = st.have && st.keep_valid && st.keep_turn == st.turns;
+    const int kn = cand ? st.keep_cur ^ 1 : 0;             // where `next` is staged; the other one holds (or will hold) `prev`
+    auto stage = [&](uint8_t *dst, const uint8_t *src, int stride) {
+        if (stride == w) memcpy(dst, src, fsz);
+        else for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * w, src + (size_t)y * stride, (size_t)w);
+    };
+    auto same_as_kept = [&]() -> bool {
+        const uint8_t *kept = st.h_keep[kn ^ 1];
+        if (stride_prev == w) return memcmp(kept, h_prev, fsz) == 0;
+        for (int y = 0; y < h; y++)
+            if (memcmp(kept + (size_t)y * w, h_prev + (size_t)y * stride_prev, (size_t)w) != 0) return false;
+        return true;
+    };
+    auto give_up = [&](int code) { st.have = false; st.keep_valid = false; (void)end_call(c, s); return code; };
+    float *d_out = c->st_flow;
+    bool direct = false;
+    if (!use_init && c->stream_zero_copy) {
+        if (void *dp = mapped_host_range(h_flow, flow_bytes)) { d_out = static_cast<float *>(dp); direct = true; }
+    }
+    // A dense `next` is uploaded from where it lies (from pageable memory the call returns once the runtime has staged it) and its
+    // byte copy is made afterwards, beside the device's work; a strided one is staged into the copy first and uploaded from there.
+    const bool next_dense = stride_next == w;
+    bool next_kept = false;
+    auto keep_next = [&]() { if (!next_kept) { stage(st.h_keep[kn], h_next, stride_next); next_kept = true; } };
+    // one turn of the session with `next`; everything enqueued, nothing waited for
+    auto enqueue_pair = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(st.d_frame, next_kept ? st.h_keep[kn] : h_next, fsz, hipMemcpyHostToDevice, s));
+        if (use_init) HIP_TRY(hipMemcpyAsync(c->st_flow, h_flow, flow_bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(c->ev0, s));
+        const int turn = stream_turn(c, s, st.d_frame, w, h, d_out, nullptr, nullptr);
+        if (turn < 0) return turn;
+        if (turn != OFARN_OK) return fail(OFARN_E_HIP, "internal: the session held no frame to pair with");
+        HIP_TRY(hipEventRecord(c->ev1, s));
+        if (!direct) HIP_TRY(hipMemcpyAsync(h_flow, c->st_flow, flow_bytes, hipMemcpyDeviceToHost, s));
+        return OFARN_OK;
+    };
+    if (!next_dense) keep_next();
+    bool reuse = false;
+    if (cand && use_init) cand = reuse = same_as_kept();    // in/out flow: nothing may be overwritten before we know
+    if (cand) {
+        if ((rc = enqueue_pair()) < 0) return give_up(rc);
+        keep_next();                                        // both beside the device's work
+        if (!use_init) reuse = same_as_kept();
+    }
+    if (!reuse) {
+        // `prev` is not what the device holds (or nothing is held): a new session from both frames.  An optimistic turn that may
+        // be running is ordered in front of this on the stream and its output is overwritten.
+        st.have = false;
+        stage(st.h_keep[kn ^ 1], h_prev, stride_prev);
+        if (hipMemcpyAsync(st.d_frame, st.h_keep[kn ^ 1], fsz, hipMemcpyHostToDevice, s) != hipSuccess)
+            return give_up(fail(OFARN_E_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(hipGetLastError())));
+        const int turn = stream_turn(c, s, st.d_frame, w, h, nullptr, nullptr, nullptr);
+        if (turn < 0) return give_up(turn);
+        if ((rc = enqueue_pair()) < 0) return give_up(rc);
+        keep_next();
+        st.reuse_misses++;
+    } else st.reuse_hits++;
+    if (hipStreamSynchronize(s) != hipSuccess) return give_up(fail(OFARN_E_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(hipGetLastError())));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms; else (void)hipGetLastError();
+    st.keep_cur = kn;
+    st.keep_valid = true;
+    st.keep_turn = st.turns;
+    if (reused) *reused = reuse ? 1 : 0;
+    return end_call(c, s);
+}
+
+int ofarn_calc_reuse_info(const ofarn_ctx *c, unsigned long long *hits, unsigned long long *misses)
+{
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    if (hits) *hits = c->stream_state.reuse_hits;
+    if (misses) *misses = c->stream_state.reuse_misses;
+    return OFARN_OK;
+}
+
+// Test hook for the device scope of the entry points (ofarn_host.h, DeviceScope): fake_current >= 0 makes every entry point believe
+// the calling thread's current device was that ordinal (no hipSetDevice back to it is issued); -1 restores normal operation.
+// Returns through the pointers, for the calling thread: scopes entered so far, and the ordinal the last scope restored (-1: none).
+int ofarn_debug_device_scope(int fake_current, int *scopes, int *last_restored)
+{
+    g_fake_current_device = fake_current;
+    if (scopes) *scopes = t_device_scopes;
+    if (last_restored) *last_restored = t_last_restored_device;
+    t_last_restored_device = -1;
+    return OFARN_OK;
+}
+
+// 1 if a flow buffer at [p, p + bytes) would be written by the GPU in place (page-locked over its whole extent), 0 if the copy path
+// is taken.  For tests: the decision can be checked without letting a kernel write anywhere.
+int ofarn_debug_mapped_host_range(const void *p, size_t bytes) { return mapped_host_range(p, bytes) != nullptr; }
+
 // The frame loop's per-frame OUTPUTS without the flow field crossing PCIe.  What the reference does with `flow` each turn is draw it:
 // draw_flow samples it on a step-14 grid and draws arrows (DenseOF.py:40-49, :574), draw_hsv paints the rainbow (DenseOF.py:109-124,
 // :578), and the danger points come from the grid filter (pathfinder_viewer.py:159-176, 204-217).  Those results are KBs (the arrow
@@ -227,6 +405,8 @@ int ofarn_stream_next_danger(ofarn_ctx *c, const uint8_t *h_gray, int w, int h, 
 int ofarn_stream_next_view(ofarn_ctx *c, const uint8_t *h_frame, int bgr, int w, int h, int stride, uint8_t *h_mask, uint8_t *h_v,
                            int arrow_step, int32_t *h_lines, uint8_t *h_rainbow)
 {
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    OFARN_ON_DEVICE(c->device);
     int rc = stream_check(c, w, h);
     if (rc) return rc;
     const int bpp = bgr ? 3 : 1;
@@ -306,7 +486,7 @@ int ofarn_stream_view_flow(ofarn_ctx *c, int w, int h, float *h_flow)
     const ofarn_ctx::Stream &st = c->stream_state;
     if (!(st.have && st.view_flow_valid && st.w == w && st.h == h) || !c->st_flow)
         return fail(OFARN_E_INVALID, "no streaming turn of %dx%d has produced a flow on this context yet", w, h);
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     int rc = begin_call(c, c->stream);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(h_flow, c->st_flow, (size_t)w * h * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -329,7 +509,7 @@ int ofarn_stream_view_lamps(ofarn_ctx *c, int w, int h, int radius, int over_fra
     int rc = lamp_grid(c, w, h, radius, &g, &P);
     if (rc) return rc;
     if (P != st.view_P) return fail(OFARN_E_INVALID, "the turn's danger map has %d points, the grid of %dx%d has %d", st.view_P, w, h, P);
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     const size_t img = (size_t)w * h * 3;
     if ((rc = grow_u8(c, &st.d_lamps, &st.lamps_cap, img, "lamp layer"))) return rc;
     hipStream_t s = c->stream;
@@ -353,7 +533,7 @@ int ofarn_stream_view_arrows(ofarn_ctx *c, int w, int h, int step, int over_fram
         return fail(OFARN_E_INVALID, "no streaming turn of %dx%d has produced a flow on this context yet", w, h);
     if (over_frame && !st.view_bgr_valid)
         return fail(OFARN_E_INVALID, "over_frame needs the turn's frame in BGR, and the most recent view turn was given a gray frame");
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     const size_t img = (size_t)w * h * 3;
     int rc = grow_u8(c, &st.d_lamps, &st.lamps_cap, img, "arrow layer");
     if (rc) return rc;
@@ -380,7 +560,7 @@ int ofarn_stream_view_rainbow(ofarn_ctx *c, int w, int h, int over_frame, uint8_
         return fail(OFARN_E_INVALID, "no streaming turn of %dx%d has produced a flow on this context yet", w, h);
     if (over_frame && !st.view_bgr_valid)
         return fail(OFARN_E_INVALID, "over_frame needs the turn's frame in BGR, and the most recent view turn was given a gray frame");
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     const size_t img = (size_t)w * h * 3;
     int rc = grow_u8(c, &st.d_lamps, &st.lamps_cap, img, "rainbow layer");
     if (rc) return rc;
@@ -398,6 +578,8 @@ int ofarn_stream_view_rainbow(ofarn_ctx *c, int w, int h, int over_frame, uint8_
 // long as the kernels themselves).
 int ofarn_stream_submit(ofarn_ctx *c, const uint8_t *h_gray, int w, int h, int stride, float *h_flow)
 {
+    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
+    OFARN_ON_DEVICE(c->device);
     int rc = stream_check(c, w, h);
     if (rc) return rc;
     if (!h_gray) return fail(OFARN_E_INVALID, "frame is NULL");
@@ -428,7 +610,13 @@ int ofarn_stream_submit(ofarn_ctx *c, const uint8_t *h_gray, int w, int h, int s
         for (int i = 0; i < 2; i++)
             if (hipEventCreateWithFlags(&st.ev_uploaded[i], hipEventDisableTiming) != hipSuccess)
                 return fail(OFARN_E_HIP, "event creation failed");
+        if (hipEventCreateWithFlags(&st.ev_src_uploaded, hipEventDisableTiming) != hipSuccess)
+            return fail(OFARN_E_HIP, "event creation failed");
     }
+    // A frame that was page-locked already is uploaded from where it lies: the caller may rewrite that buffer (a capture loop
+    // reading every frame into one pinned_empty() array) once ofarn_stream_submit has been called AGAIN or ofarn_stream_wait has
+    // returned -- both wait here for the previous turn's upload, which finished long ago in any loop that does work in between.
+    if (st.src_uploaded_valid) { HIP_TRY(hipEventSynchronize(st.ev_src_uploaded)); st.src_uploaded_valid = false; }
     if (fsz * 2 > st.ring_cap) {
         HIP_TRY(hipStreamSynchronize(st.copy_stream));            // a transfer may still read the old buffers
         for (int i = 0; i < ofarn_ctx::Stream::kRing; i++) {
@@ -486,6 +674,7 @@ int ofarn_stream_submit(ofarn_ctx *c, const uint8_t *h_gray, int w, int h, int s
         if (sstride == w) HIP_TRY(hipMemcpyAsync(st.d_frame, src, fsz, hipMemcpyHostToDevice, s));
         else HIP_TRY(hipMemcpy2DAsync(st.d_frame, w, src, sstride, w, h, hipMemcpyHostToDevice, s));
         if (k >= 0) { HIP_TRY(hipEventRecord(st.ev_uploaded[k], s)); st.uploaded_valid[k] = true; }
+        else { HIP_TRY(hipEventRecord(st.ev_src_uploaded, s)); st.src_uploaded_valid = true; }
     }
     // No side stream for stages A + B here: the previous turn's transfer is running on the copy stream, and a THIRD hardware queue in
     // play means that -- depending on which queues the driver happens to put on one pipe -- the level builds can sit behind the
@@ -501,14 +690,8 @@ int ofarn_stream_submit(ofarn_ctx *c, const uint8_t *h_gray, int w, int h, int s
         HIP_TRY(hipStreamWaitEvent(st.copy_stream, st.ev_computed[slot], 0));
         // page-locked destination: pushed by a small kernel that leaves the CUs to the next turn (see k_push_host); else a plain copy
         void *mapped = nullptr;
-        if (c->push_blocks > 0 && (fsz * 2) % 4 == 0 && ((uintptr_t)h_flow & 15) == 0) {
-            hipPointerAttribute_t at;
-            if (!(hipPointerGetAttributes(&at, h_flow) == hipSuccess && at.type == hipMemoryTypeHost &&
-                  hipHostGetDevicePointer(&mapped, h_flow, 0) == hipSuccess && mapped)) {
-                (void)hipGetLastError();
-                mapped = nullptr;
-            }
-        }
+        if (c->push_blocks > 0 && (fsz * 2) % 4 == 0 && ((uintptr_t)h_flow & 15) == 0)
+            mapped = mapped_host_range(h_flow, fsz * 2 * sizeof(float));
         if (mapped) launch_push_host(st.copy_stream, st.ring[slot], static_cast<float *>(mapped), fsz * 2, c->push_blocks);
         else HIP_TRY(hipMemcpyAsync(h_flow, st.ring[slot], fsz * 2 * sizeof(float), hipMemcpyDeviceToHost, st.copy_stream));
         HIP_TRY(hipEventRecord(st.ev_copied[slot], st.copy_stream));
@@ -524,8 +707,9 @@ int ofarn_stream_wait(ofarn_ctx *c, int leave_in_flight)
     if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
     constexpr int K = ofarn_ctx::Stream::kRing;
     if (leave_in_flight < 0 || leave_in_flight >= K) return fail(OFARN_E_INVALID, "leave_in_flight must be in [0, %d]", K - 1);
-    HIP_TRY(hipSetDevice(c->device));
+    OFARN_ON_DEVICE(c->device);
     ofarn_ctx::Stream &st = c->stream_state;
+    if (st.src_uploaded_valid) { HIP_TRY(hipEventSynchronize(st.ev_src_uploaded)); st.src_uploaded_valid = false; }
     if (leave_in_flight > 0) {
         // everything but the `leave_in_flight` most recent turns: turn n (0-based) used slot n % K; transfers complete in order, so
         // waiting for the newest turn that must be complete is enough
@@ -549,12 +733,18 @@ int ofarn_host_alloc(size_t bytes, void **out)
         *out = nullptr;
         return fail(OFARN_E_NOMEM, "pinned host buffer of %zu bytes could not be allocated", bytes);
     }
+    std::lock_guard<std::mutex> lk(g_pins_mu);
+    g_pins[(uintptr_t)*out] = bytes ? bytes : 1;
     return OFARN_OK;
 }
 
 int ofarn_host_free(void *p)
 {
     if (!p) return OFARN_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_pins_mu);
+        g_pins.erase((uintptr_t)p);
+    }
     HIP_TRY(hipHostFree(p));
     return OFARN_OK;
 }

@@ -29,6 +29,38 @@ int fail(int code, const char *fmt, ...);
                         __FILE__, __LINE__);                                                  \
     } while (0)
 
+// Every entry point runs on its context's device and leaves the caller's current device as it found it (a host application with
+// its own device state must not notice the library).  OFARN_ON_DEVICE(dev) at the top of an entry point: switches if needed,
+// switches back when the entry point returns -- on every path.  Helpers called from entry points use plain hipSetDevice.
+// Test hook (one GPU boxes cannot observe a switch): ofarn_debug_device_scope() makes the scope believe the caller was on another
+// ordinal and reports the ordinal it restored.
+extern int g_fake_current_device;              // -1: ask hipGetDevice
+extern thread_local int t_last_restored_device, t_device_scopes;
+struct DeviceScope {
+    int before = -1;
+    bool restore = false, fake = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int device)
+    {
+        t_device_scopes++;
+        if (g_fake_current_device >= 0) { before = g_fake_current_device; fake = true; }
+        else if (hipGetDevice(&before) != hipSuccess) { (void)hipGetLastError(); before = -1; }
+        if (before != device) { err = hipSetDevice(device); restore = before >= 0; }
+    }
+    ~DeviceScope()
+    {
+        if (!restore) return;
+        t_last_restored_device = before;
+        if (!fake) (void)hipSetDevice(before);
+    }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+#define OFARN_ON_DEVICE(device)                                                                              \
+    ofarn_host::DeviceScope device_scope_(device);                                                           \
+    if (device_scope_.err != hipSuccess)                                                                     \
+        return ofarn_host::fail(OFARN_E_HIP, "hipSetDevice(%d) failed: %s", (int)(device), hipGetErrorString(device_scope_.err))
+
 // device scratch that lives for one host-pointer call
 struct DevTmp {
     void *p = nullptr;
@@ -147,6 +179,15 @@ struct ofarn_ctx {
         hipEvent_t ev_uploaded[2] = {nullptr, nullptr};
         bool uploaded_valid[2] = {false, false};
         unsigned long long stages = 0;
+        hipEvent_t ev_src_uploaded = nullptr;   // behind the upload of a frame that was page-locked already (read in place): the next
+        bool src_uploaded_valid = false;        // submit / wait makes sure it has been read before the caller may rewrite it
+        // ofarn_calc_reuse: byte copies of the frames the session was last given, page-locked (they double as upload staging);
+        // h_keep[keep_cur] equals the frame in R slot `cur` iff keep_valid && keep_turn == turns
+        uint8_t *h_keep[2] = {nullptr, nullptr};
+        size_t keep_cap = 0;
+        int keep_cur = 0;
+        bool keep_valid = false;
+        unsigned long long keep_turn = 0, reuse_hits = 0, reuse_misses = 0;
     } stream_state;
     int stream_overlap = 2;             // streaming turn: stages A + B on an internal stream beside the iteration chain (run_wave);
                                         // 1: the chain waits behind every level's expansion, 2: behind the coarsest and every second one
@@ -188,6 +229,9 @@ inline hipStream_t pick_stream(const ofarn_ctx *c, void *hip_stream)
     return hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
 }
 
+// ofarn_api_stream.hip: the device-side address of a page-locked host range [p, p + bytes), or nullptr when p is not page-locked
+// or the allocation it lies in does not cover the whole range (the caller then takes the copy path).
+void *mapped_host_range(const void *p, size_t bytes);
 // ofarn_api_extras.hip: np.mgrid[step/2:size:step] of draw_flow (DenseOF.py:44): count and float start
 int arrow_axis(int size, int step, double *start);
 // Lamp layer geometry for w x h frames on the context's measurement grid; OFARN_E_* if the discs would touch or the radius is out of range

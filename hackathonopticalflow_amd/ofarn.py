@@ -73,6 +73,10 @@ ABI = {
     "ofarn_destroy": (None, [C.c_void_p]),
     "ofarn_last_error": (C.c_char_p, []),
     "ofarn_calc": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _fp]),
+    "ofarn_calc_reuse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, _ip]),
+    "ofarn_calc_reuse_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+    "ofarn_debug_device_scope": (C.c_int, [C.c_int, _ip, _ip]),
+    "ofarn_debug_mapped_host_range": (C.c_int, [C.c_void_p, C.c_size_t]),
     "ofarn_calc_batch": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _u8p, _u8p]),
     "ofarn_calc_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -146,6 +150,7 @@ ABI = {
     "ofarn_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "ofarn_host_free": (C.c_int, [C.c_void_p]),
     "ofarn_shard_pairs": (C.c_int, [C.c_int, C.c_int, C.c_int, _ip, _ip]),
+    "ofarn_gather_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ofarn_multi_create": (C.c_int, [C.POINTER(OfarnParams), _ip, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "ofarn_multi_destroy": (None, [C.c_void_p]),
     "ofarn_multi_device_count": (C.c_int, [C.c_void_p]),
@@ -470,6 +475,30 @@ class FarnebackEngine:
                 raise ValueError(f"OPTFLOW_USE_INITIAL_FLOW needs `flow` (float32[{h},{w},2]) holding the initial flow")
             return np.array(flow, np.float32, order="C")
         return np.empty((h, w, 2), np.float32)
+
+    def calc_reuse(self, prev, next, flow=None, return_reused=False):
+        """calc() for consecutive pairs (the reference's loop, DenseOF.py:519-525): same result as calc(prev, next) for every
+        input.  The context holds a byte copy of the frame it last saw as `next`; when `prev` equals it -- every byte compared
+        by ofarn_calc_reuse, beside the device's work -- the frame on the device is reused and only `next` is uploaded."""
+        prev_a, next_a = _as_gray(prev, "prev"), _as_gray(next, "next")
+        if prev_a.shape != next_a.shape:
+            raise ValueError(f"prev and next must have the same size, got {prev_a.shape} and {next_a.shape}")
+        h, w = prev_a.shape
+        if prev_a.strides[1] != 1 or prev_a.strides[0] < w:
+            prev_a = np.ascontiguousarray(prev_a)
+        if next_a.strides[1] != 1 or next_a.strides[0] < w:
+            next_a = np.ascontiguousarray(next_a)
+        out = self._flow_out(flow, h, w)
+        reused = C.c_int(0)
+        _check(self._lib.ofarn_calc_reuse(self._h, C.c_void_p(prev_a.ctypes.data), C.c_void_p(next_a.ctypes.data), w, h,
+                                          prev_a.strides[0], next_a.strides[0], C.c_void_p(out.ctypes.data), C.byref(reused)))
+        return (out, bool(reused.value)) if return_reused else out
+
+    def reuse_info(self):
+        """(hits, misses) of calc_reuse on this context."""
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        _check(self._lib.ofarn_calc_reuse_info(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def stream_next(self, frame, flow=None, want_danger=False):
         """One turn of the reference's frame loop: hands over the NEW frame only; the previous one is held on the device.
@@ -1058,6 +1087,29 @@ class MultiGpuEngine:
     def synchronize(self):
         _check(self._lib.ofarn_multi_synchronize(self._h))
 
+    def _rank_ctx(self, rank):
+        h = self._lib.ofarn_multi_context(self._h, int(rank))
+        if not h:
+            raise ValueError(f"rank {rank} out of range [0, {len(self.devices)})")
+        return C.c_void_p(h)
+
+    def rank_profile_enable(self, rank, on=True):
+        """Per-kernel hipEvent timing of ONE device's context (the contexts are owned by the ofarn_multi; nothing is created here)."""
+        _check(self._lib.ofarn_profile_enable(self._rank_ctx(rank), int(bool(on))))
+
+    def rank_profile_read(self, rank):
+        cap = len(FarnebackEngine.STAGES) * 32
+        st, lv, ln = (C.c_int * cap)(), (C.c_int * cap)(), (C.c_int * cap)()
+        ms, un = (C.c_double * cap)(), (C.c_double * cap)()
+        n = self._lib.ofarn_profile_read(self._rank_ctx(rank), cap, st, lv, ln, ms, un)
+        if n < 0:
+            _raise(n)
+        return [dict(stage=FarnebackEngine.STAGES[st[i]], level=lv[i], launches=ln[i], ms=ms[i], units=un[i])
+                for i in range(min(n, cap))]
+
+    def rank_workspace_bytes(self, rank) -> int:
+        return int(self._lib.ofarn_workspace_bytes(self._rank_ctx(rank)))
+
     def info(self):
         ver, calls, ms = C.c_int(), C.c_ulonglong(), C.c_double()
         _check(self._lib.ofarn_multi_info(self._h, C.byref(ver), C.byref(calls), C.byref(ms)))
@@ -1234,7 +1286,7 @@ _engines_lock = threading.Lock()
 _SLOTS_PER_KEY = 2           # contexts per (shape, device, parameters): two threads with the same shape do not serialise
 
 
-_DROPIN_REUSE = os.environ.get("OFARN_DROPIN_REUSE", "1") != "0"   # 0: the drop-in never reuses the previous call's frame
+_DROPIN_REUSE = os.environ.get("OFARN_DROPIN_REUSE", "1") != "0"   # 0: every call uploads and expands both frames (no frame is held)
 _DROPIN_PINNED = os.environ.get("OFARN_DROPIN_PINNED", "1") != "0"  # 0: the drop-in returns plain np.empty arrays
 
 
@@ -1304,44 +1356,27 @@ class _PinnedPool:
 _dropin_pool = _PinnedPool()
 
 
-def _frame_signature(a: np.ndarray):
-    """Cheap fingerprint of a frame: identity of the buffer plus a checksum of every 16th row (summed as 64-bit words where the
-    layout allows: ~6 us at 1080p, twice per call).  It is only ever compared for the SAME array object, to notice that the caller
-    has overwritten it in place between two calls (the reference never does: DenseOF.py:510 makes a fresh `gray` per frame).  A
-    change confined to the rows in between would go unnoticed; a full comparison would cost more than the reuse saves.
-    OFARN_DROPIN_REUSE=0 switches the reuse off."""
-    addr = a.__array_interface__["data"][0]
-    rows = a[::16]
-    if a.ndim == 2 and a.dtype == np.uint8 and a.strides[1] == 1 and a.shape[1] % 8 == 0 and a.strides[0] % 8 == 0 and addr % 8 == 0:
-        chk = int(rows.view(np.uint64).sum(dtype=np.uint64))
-    else:
-        chk = int(rows.sum(dtype=np.int64))
-    return (addr, a.shape, a.strides, chk)
-
-
 class _Slot:
-    """One cached context + the lock that serialises its users (an ofarn_ctx must not be used from two threads at once) + what
-    its streaming session holds: a weak reference to the array object that was `next` in the last call and its fingerprint."""
-    __slots__ = ("eng", "lock", "last_ref", "last_sig")
+    """One cached context + the lock that serialises its users (an ofarn_ctx must not be used from two threads at once) + a weak
+    reference to the array object that was `next` in its last call.  The reference is a HINT for choosing among the contexts of a
+    key (the one whose session probably holds the caller's `prev`); whether the held frame really equals `prev` is decided by
+    ofarn_calc_reuse, which compares every byte."""
+    __slots__ = ("eng", "lock", "last_ref")
 
     def __init__(self, eng):
         self.eng = eng
         self.lock = threading.Lock()
         self.last_ref = None
-        self.last_sig = None
 
     def is_last(self, prev) -> bool:
         """`prev` is the array object this slot's session saw last (identity only: no look at the data)."""
-        return _DROPIN_REUSE and self.last_ref is not None and self.last_ref() is prev
-
-    def holds(self, prev) -> bool:
-        return self.is_last(prev) and isinstance(prev, np.ndarray) and self.last_sig == _frame_signature(prev)
+        return self.last_ref is not None and self.last_ref() is prev
 
     def remember(self, nxt):
         try:
-            self.last_ref, self.last_sig = weakref.ref(nxt), _frame_signature(nxt)
-        except TypeError:                     # not weak-referenceable (not an ndarray): no reuse next time
-            self.last_ref = self.last_sig = None
+            self.last_ref = weakref.ref(nxt)
+        except TypeError:                     # not weak-referenceable (not an ndarray)
+            self.last_ref = None
 
 
 class _CachedEngines:
@@ -1429,25 +1464,23 @@ def calculate_optical_flow(prev, next, flow=None, pyr_scale=0.5, levels=3, winsi
                         iterations=int(iterations), poly_n=int(poly_n), poly_sigma=float(poly_sigma), flags=int(flags))
     with lease as eng:
         # The reference calls this once per frame with prev = the array that was `next` one call earlier (DenseOF.py:519-525:
-        # prev_gray = gray).  The context's streaming session then still holds that frame on the device -- level images and
-        # polynomial expansions included -- and only `next` is uploaded and expanded.  Anything else (another array, the same
-        # array overwritten in place, another thread's context) starts a new session from `prev`: same result, no saving.
+        # prev_gray = gray).  The context then still holds that frame on the device -- level images and polynomial expansions
+        # included -- and only `next` is uploaded and expanded.  That the held frame IS `prev` is established by comparing all of
+        # its bytes with a host copy (ofarn_calc_reuse; the comparison runs beside the device's work): a `prev` edited in place
+        # anywhere, another array, another thread's context all start over from both frames.  Same result either way -- the
+        # function is as stateless as cv2's.  OFARN_DROPIN_REUSE=0: never hold a frame.
         slot = lease.slot
-        if not (slot.holds(prev) and eng.stream_primed(w, h)):
+        if not _DROPIN_REUSE:
             eng.stream_reset()
-            eng.stream_next(prev_a)
         if flow is None and not (int(flags) & OPTFLOW_USE_INITIAL_FLOW):
             flow = _dropin_pool.take(h, w)              # page-locked, recycled once the caller has dropped the previous result
         try:
-            out = eng.stream_next(next_a, flow)
+            out = eng.calc_reuse(prev_a, next_a, flow)
         except Exception:
-            slot.last_ref = slot.last_sig = None
+            slot.last_ref = None
             eng.stream_reset()
             raise
-        if isinstance(next, np.ndarray):
-            slot.remember(next)
-        else:
-            slot.last_ref = slot.last_sig = None
+        slot.remember(next) if isinstance(next, np.ndarray) else setattr(slot, "last_ref", None)
         return out
 
 

@@ -92,6 +92,20 @@ const char *ofarn_last_error(void);
 int ofarn_calc(ofarn_ctx *ctx, const uint8_t *h_prev, const uint8_t *h_next, int w, int h,
                int stride, float *h_flow);
 
+/* ofarn_calc for a caller that passes consecutive pairs, as the reference's loop does (DenseOF.py:519-525:
+ *     flow = calculate_optical_flow(prev=prev_gray, next=gray); prev_gray = gray),
+ * with ofarn_calc's contract: the result depends on (prev, next) alone and equals ofarn_calc's bit for bit for EVERY input.
+ * The context keeps a page-locked byte copy of the frame it was last given as `next` (it doubles as the upload's staging
+ * buffer).  When all w x h bytes of `prev` equal that copy, the frame already on the device -- with its level images and
+ * polynomial expansions -- is reused and only `next` is uploaded and expanded; otherwise both are.  The comparison is a full
+ * memcmp on the host, run while the device already computes the turn it would allow (redone from both frames if it fails).
+ * Rows of prev / next are stride_prev / stride_next bytes apart.  *reused (may be NULL): 1 if the held frame was reused.
+ * h_flow as in ofarn_calc (in/out with OPTFLOW_USE_INITIAL_FLOW; a page-locked buffer is written by the last kernel). */
+int ofarn_calc_reuse(ofarn_ctx *ctx, const uint8_t *h_prev, const uint8_t *h_next, int w, int h, int stride_prev,
+                     int stride_next, float *h_flow, int *reused);
+/* How often ofarn_calc_reuse reused the held frame / started over from both frames on this context (either may be NULL). */
+int ofarn_calc_reuse_info(const ofarn_ctx *ctx, unsigned long long *hits, unsigned long long *misses);
+
 /* A batch of frames, host memory; synchronous.  h_frames: uint8[n_frames][h][w] dense.
  * Any of h_flow (float32[n_pairs][h][w][2]), h_mask, h_v (uint8[n_pairs][P]) may be NULL.
  * Replaces: the per-frame loop DenseOF.py:491-525 plus the filter pathfinder_viewer.py:159-176
@@ -169,7 +183,10 @@ int ofarn_stream_wait(ofarn_ctx *ctx, int leave_in_flight);
 int ofarn_stream_reset(ofarn_ctx *ctx);
 /* 1 if the session holds a frame of this size (the next ofarn_stream_next* call will produce a flow), else 0. */
 int ofarn_stream_primed(const ofarn_ctx *ctx, int w, int h);
-/* Page-locked host memory for frames and flow fields (hipHostMalloc): transfers to and from it need no staging copy. */
+/* Page-locked host memory for frames and flow fields (hipHostMalloc): transfers to and from it need no staging copy.  A flow
+ * buffer is written by the GPU in place only when the page-locked allocation covers all of [h_flow, h_flow + 8 w h): blocks from
+ * ofarn_host_alloc are checked against their own extent, page-locked memory from elsewhere against the runtime's
+ * (hipMemGetAddressRange); anything else -- including a pointer too close to the end of a page-locked block -- takes the copy. */
 int ofarn_host_alloc(size_t bytes, void **out);
 int ofarn_host_free(void *p);
 
@@ -280,6 +297,15 @@ int ofarn_draw_vectors_device(ofarn_ctx *ctx, const int32_t *d_iflow, const uint
 typedef struct ofarn_multi ofarn_multi;
 /* Contiguous, balanced shard: the first n_pairs % world ranks get one pair more.  Pure arithmetic (no GPU). */
 int ofarn_shard_pairs(int n_pairs, int rank, int world, int *start, int *count);
+/* Every index of a multi-device batch, pure arithmetic (no GPU; this is what ofarn_multi_calc_batch* computes with).  Arrays of
+ * `world` entries (any may be NULL): start / count = the shards; gather_off[r] = byte offset of rank r's rows in the padded all-gather
+ * array uint8[world][cap][P] (every rank contributes cap = max count rows; the gather is in place, send = receive + gather_off[r]);
+ * global_off[r] = byte offset of rank r's rows in the compact uint8[n_pairs][P] array.  *even: every shard is full, the padded
+ * array is the compact one and nothing is moved; otherwise count[r] * P bytes go from gather_off[r] to global_off[r]. */
+int ofarn_gather_plan(int n_pairs, int world, int P, int *start, int *count, int *cap, int *even, uint64_t *gather_off,
+                      uint64_t *global_off);
+/* One persistent host thread per device is created here and joined by ofarn_multi_destroy; all device work of the ofarn_multi_*
+ * entry points runs on those threads, so the calling thread's current HIP device is never changed. */
 /* devices: n_devices distinct HIP device ordinals (NULL = 0 .. n_devices-1); each gets a context for waves of up to
  * max_batch_per_device pairs. */
 int ofarn_multi_create(const ofarn_params *params, const int *devices, int n_devices, int max_w, int max_h,
@@ -361,6 +387,15 @@ double ofarn_last_device_ms(const ofarn_ctx *ctx);
 int ofarn_profile_enable(ofarn_ctx *ctx, int on);
 int ofarn_profile_read(ofarn_ctx *ctx, int cap, int *stage, int *level, int *launches, double *ms,
                        double *units);
+
+/* Every entry point that takes a context runs on the context's device and leaves the calling thread's current HIP device as it
+ * found it.  Test hook for that (a one-GPU box cannot observe a switch): fake_current >= 0 makes the entry points believe the calling
+ * thread was on that ordinal (no hipSetDevice back to it is issued), -1 ends it; *scopes = entry points entered by the calling
+ * thread so far, *last_restored = the ordinal the most recent one switched back to (-1: it had nothing to restore). */
+int ofarn_debug_device_scope(int fake_current, int *scopes, int *last_restored);
+
+/* 1 if a host buffer [p, p + bytes) would be written by the GPU in place (see ofarn_host_alloc), 0 if results are copied into it. */
+int ofarn_debug_mapped_host_range(const void *p, size_t bytes);
 
 /* Bytes of HBM workspace held by the context right now.  The polynomial-expansion and flow buffers are sized for
  * max_batch pairs by ofarn_create; level-image, row-pass and (unfused paths only) matrix buffers are allocated by the

@@ -155,3 +155,78 @@ def test_gather_at_world_size_one_is_allocation_free():
     assert q.get(timeout=120) is True
     p.join(timeout=60)
     assert p.exitcode == 0
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("n_pairs", [0, 1, 5, 8, 13, 64, 67, 512])
+def test_c_abi_gather_plan_against_the_python_mirror(n_pairs, world):
+    """the G > 1 branches of ofarn_multi_* (in-place all-gather at rank * cap * P, the `even` shortcut, compaction of
+    ragged shards) cannot run on a one-GPU box.  Their index arithmetic lives in one host-only function (ofarn_gather_plan); here it
+    is checked on the CPU for ragged and even pair counts against the Python mirror, and the whole data movement is replayed with
+    NumPy: every rank's rows written at gather_off[rank] of a padded array, "all-gathered", compacted to global_off -- the result
+    must be the maps in global pair order on every rank."""
+    import ctypes as C
+    from hackathonopticalflow_amd import ofarn
+    lib = ofarn.load_library()
+    P = 37
+    start, count = (C.c_int * world)(), (C.c_int * world)()
+    goff, xoff = (C.c_uint64 * world)(), (C.c_uint64 * world)()
+    cap, even = C.c_int(), C.c_int()
+    assert lib.ofarn_gather_plan(n_pairs, world, P, start, count, C.byref(cap), C.byref(even), goff, xoff) == 0
+    spans = [D.shard_pairs(n_pairs, r, world) for r in range(world)]
+    assert [(start[r], count[r]) for r in range(world)] == spans
+    assert cap.value == max(c for _, c in spans)
+    assert bool(even.value) == (n_pairs == cap.value * world)
+    assert [goff[r] for r in range(world)] == [r * cap.value * P for r in range(world)]
+    assert [xoff[r] for r in range(world)] == [spans[r][0] * P for r in range(world)]
+    # replay: what the devices do with these offsets
+    rng = np.random.default_rng(n_pairs * 31 + world)
+    full = rng.integers(0, 256, (n_pairs, P)).astype(np.uint8)
+    padded_bytes = world * cap.value * P
+    per_rank = []
+    for r in range(world):                                   # phase 1: each rank writes its shard at its own rows of its own buffer
+        buf = np.full(padded_bytes, 0xEE, np.uint8)
+        s, c = spans[r]
+        buf[goff[r]:goff[r] + c * P] = full[s:s + c].ravel()
+        per_rank.append(buf)
+    gathered = np.full(padded_bytes, 0xEE, np.uint8)         # phase 2: in-place all-gather = every rank's cap * P block, in rank order
+    for r in range(world):
+        gathered[goff[r]:goff[r] + cap.value * P] = per_rank[r][goff[r]:goff[r] + cap.value * P]
+    if even.value:                                           # the padded array IS the global one
+        np.testing.assert_array_equal(gathered.reshape(n_pairs, P), full)
+    else:                                                    # phase 3: compaction
+        out = np.zeros(n_pairs * P, np.uint8)
+        for r in range(world):
+            c = spans[r][1]
+            out[xoff[r]:xoff[r] + c * P] = gathered[goff[r]:goff[r] + c * P]
+        np.testing.assert_array_equal(out.reshape(n_pairs, P), full)
+    # the torch.distributed form's gather (DangerGather's layout) agrees with it
+    parts = [full[s:s + c] for s, c in spans]
+    m, _ = D.FakeCommunicator(world).gather(parts, parts, n_pairs)
+    np.testing.assert_array_equal(m, full)
+    assert lib.ofarn_gather_plan(-1, world, P, None, None, None, None, None, None) < 0
+    assert lib.ofarn_gather_plan(4, 0, P, None, None, None, None, None, None) < 0
+
+
+def test_bench_inproc_argument_plumbing():
+    """`bench.py --multi inproc`: shards per device for configs 3 (weak), 4 and 5 (strong) and the argument checks that need no GPU."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    g, sh = bench.inproc_shards(bench.CONFIGS[3], 8)
+    assert g == 4096 and sh == [(512 * r, 512) for r in range(8)]
+    g, sh = bench.inproc_shards(bench.CONFIGS[4], 8)
+    assert g == 512 and sh == [(64 * r, 64) for r in range(8)]
+    g, sh = bench.inproc_shards(bench.CONFIGS[5], 8)
+    assert g == 64 and sh == [(8 * r, 8) for r in range(8)]
+    g, sh = bench.inproc_shards(bench.CONFIGS[4], 3, batch=10)
+    assert g == 10 and sh == [(0, 4), (4, 3), (7, 3)]
+    with pytest.raises(ValueError):
+        bench.inproc_shards(bench.CONFIGS[5], 8, batch=5)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--multi", "inproc", "--gpus", "2"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "ONE process" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--multi", "inproc", "--config", "2"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "configs 3, 4, 5" in r.stderr

@@ -2,10 +2,12 @@
 all-gather of the danger maps.  The GPU box has one MI355X: the n = 1 leg runs the whole path -- ncclCommInitAll, the
 in-place ncclAllGather inside an RCCL group, the shard arithmetic with world = 1 -- and must equal ofarn_calc_batch bit for bit.
 With more devices visible the same tests run on all of them."""
+import os
+
 import numpy as np
 import pytest
 
-from hackathonopticalflow_amd.synth import translated_pairs, warped_pairs
+from hackathonopticalflow_amd.synth import translated_pair, translated_pairs, warped_pairs
 
 pytestmark = pytest.mark.gpu
 
@@ -125,3 +127,69 @@ def test_c_program_stream_and_multi(H, oracle, tmp_path):
         ref = oracle.farneback(frames[i], frames[i + 1], levels=3, box_mode=oracle.BOX_BLOCKED)
         np.testing.assert_array_equal(fs[i], ref)
         np.testing.assert_array_equal(mask[i], oracle.danger_map_numpy(ref, w, h, 30)[0])
+
+
+@pytest.mark.parametrize("config,batch", [(3, 16), (4, 16), (5, 2)])
+def test_bench_inproc_at_one_device(config, batch):
+    """SURVEY 8(e) as written has a bench line -- `bench.py --multi inproc --gpus N`: one process,
+    MultiGpuEngine.calc_batch_device in the timed region (device-resident shards, the in-place ncclAllGather group inside).  At
+    N = 1 (what this box has) the value must be that of the single-context line on the same box (within a few per cent at this small
+    batch; the full-size comparison is profiles/r04_bench_inproc_config3.json vs r04_bench_final.json), the gather check true, the
+    collective counted, same JSON schema."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    common = ["--config", str(config), "--batch", str(batch), "--steps", "4", "--warmup", "2", "--cpu-sample", "0", "--no-family-check",
+              "--no-two-stream"]
+    outs = {}
+    for mode in ("inproc", "ranks"):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--multi", mode] + common
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", f"bench_{mode}_n1_config{config}.log"), "w") as f:
+            f.write("$ " + " ".join(cmd) + "\n" + r.stdout + "\n---- stderr ----\n" + r.stderr[-4000:])
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        outs[mode] = json.loads(lines[0])
+    a, b = outs["inproc"], outs["ranks"]
+    assert a["n_gpus"] == 1 and a["ranks"] == 1 and a["scaling"] == b["scaling"] and a["metric"] == b["metric"] and a["unit"] == b["unit"]
+    assert a["config"]["parallelism"] == "1 devices in one process, ncclCommInitAll"
+    assert a["config"]["global_pairs"] == batch and a["config"]["pairs_per_gpu"] == batch
+    assert a["gathered_danger_maps_checked"] is True
+    assert a["collective"]["calls"] == 2 * 4 and a["collective"]["world"] == 1          # mask + V, one group per step
+    assert a["roofline"]["frac"] <= 1.0 and a["roofline"]["kernel"].startswith("flow_iter")
+    assert set(b) - {"two_stream_pairs_per_s", "other_family"} <= set(a) | {"cpu_baseline", "parity"}
+    assert abs(a["value"] / b["value"] - 1) < 0.10, (a["value"], b["value"])
+
+
+def test_multi_leaves_the_callers_device_and_thread_alone(H, oracle):
+    """ofarn_multi_* does all device work on its persistent per-device worker threads (created by ofarn_multi_create, joined by
+    ofarn_multi_destroy): the calling thread's current device is never changed -- checked with the device-scope hook, which would
+    record a restore if any ofarn_ctx entry point ran on the CALLING thread -- and the number of threads of the process does not
+    grow from call to call (round 3 started 2 x G threads per call)."""
+    import ctypes as C
+    import threading
+    lib = H.load_library()
+    frames = np.stack([f for s in (1, 2, 3) for f in translated_pair(120, 160, s, max_shift=2)[:2]])
+    scopes, restored = C.c_int(0), C.c_int(0)
+    with H.MultiGpuEngine([0], 160, 120, 4, levels=2) as eng:
+        eng.calc_batch(frames)
+        n_threads = threading.active_count()
+        os_threads = len(os.listdir("/proc/self/task"))
+        lib.ofarn_debug_device_scope(-1, C.byref(scopes), C.byref(restored))
+        n0 = scopes.value
+        for _ in range(5):
+            flow, mask, v = eng.calc_batch(frames)
+        lib.ofarn_debug_device_scope(-1, C.byref(scopes), C.byref(restored))
+        assert scopes.value == n0                     # no context entry point ran on this thread
+        assert threading.active_count() == n_threads and len(os.listdir("/proc/self/task")) <= os_threads + 1
+    with H.FarnebackEngine(160, 120, 4, levels=2) as single:
+        f1, m1, v1 = single.calc_batch(frames)
+    np.testing.assert_array_equal(flow, f1)
+    np.testing.assert_array_equal(mask, m1)
+    np.testing.assert_array_equal(v, v1)

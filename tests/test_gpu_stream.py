@@ -184,39 +184,122 @@ def test_initial_flow_warm_start(H, oracle):
             prev_flow = got
 
 
-def test_drop_in_reuses_the_previous_frame(H, oracle, monkeypatch):
-    """calculate_optical_flow called as the reference does (prev = the array that was `next` one call earlier) uploads and
-    expands only the new frame; any other call pattern -- a different array, the same array overwritten in place -- starts a
-    new session.  Results are the oracle's either way."""
+def _dropin_reuse_counts(H):
+    """(hits, misses) of ofarn_calc_reuse summed over every context the drop-in has cached."""
+    from hackathonopticalflow_amd import ofarn
+    hits = misses = 0
+    with ofarn._engines_lock:
+        slots = [sl for e in ofarn._engines.values() for sl in e.slots if sl.eng is not None]
+    for sl in slots:
+        a, b = sl.eng.reuse_info()
+        hits, misses = hits + a, misses + b
+    return hits, misses
+
+
+def test_drop_in_reuses_the_previous_frame(H, oracle):
+    """calculate_optical_flow called as the reference does (prev = the frame that was `next` one call earlier) uploads and
+    expands only the new frame -- decided by comparing every byte of `prev` with a host copy of the held frame; a `prev` with
+    other bytes starts over from both frames.  Results are the oracle's either way (DenseOF.py:127-157 is a pure function)."""
     H.close_cached_engines()
-    resets = []
-    orig = H.FarnebackEngine.stream_reset
-    monkeypatch.setattr(H.FarnebackEngine, "stream_reset", lambda self: (resets.append(1), orig(self))[1])
     fr = [f.copy() for f in video(6, 120, 160, 23)]
     ref = lambda p, n: oracle.farneback(p, n, levels=2, box_mode=oracle.BOX_BLOCKED)
     prev = fr[0]
     for i in range(1, 4):                                   # the reference's loop
         np.testing.assert_array_equal(H.calculate_optical_flow(prev, fr[i], levels=2), ref(prev, fr[i]))
         prev = fr[i]
-    assert len(resets) == 1                                 # only the very first call had to start a session
-    # a copy of the right frame is another object: correct, no reuse
+    assert _dropin_reuse_counts(H) == (2, 1)                # only the very first call had to upload both frames
+    # a copy of the held frame is another object with the same bytes: reused (what counts is the content)
     np.testing.assert_array_equal(H.calculate_optical_flow(fr[3].copy(), fr[4], levels=2), ref(fr[3], fr[4]))
-    assert len(resets) == 2
-    # the held frame overwritten in place: noticed (checksum of every 8th row), correct
+    assert _dropin_reuse_counts(H) == (3, 1)
+    # the held frame overwritten in place: noticed, correct
     keep = fr[4].copy()
     fr[4][:] = fr[0]
     np.testing.assert_array_equal(H.calculate_optical_flow(fr[4], fr[5], levels=2), ref(fr[0], fr[5]))
-    assert len(resets) == 3
+    assert _dropin_reuse_counts(H) == (3, 2)
     fr[4][:] = keep
     # other parameters -> another context; then back: the first context still holds fr[5]
     np.testing.assert_array_equal(H.calculate_optical_flow(fr[1], fr[2], levels=1), oracle.farneback(fr[1], fr[2], levels=1, box_mode=oracle.BOX_BLOCKED))
-    n0 = len(resets)
+    h0, m0 = _dropin_reuse_counts(H)
     np.testing.assert_array_equal(H.calculate_optical_flow(fr[5], fr[0], levels=2), ref(fr[5], fr[0]))
-    assert len(resets) == n0
+    assert _dropin_reuse_counts(H) == (h0 + 1, m0)
+    # another entry point moves the session in between: the held copy no longer describes it -> both frames again, correct
+    from hackathonopticalflow_amd import ofarn
+    with ofarn._engine_for(120, 160, 0, pyr_scale=0.5, levels=2, winsize=15, iterations=3, poly_n=5, poly_sigma=1.2, flags=0) as eng:
+        eng.stream_next(fr[3])
+    np.testing.assert_array_equal(H.calculate_optical_flow(fr[0], fr[2], levels=2), ref(fr[0], fr[2]))
+    assert _dropin_reuse_counts(H) == (h0 + 1, m0 + 1)
+    # strided views (a crop of a larger frame) on either side
+    big = np.zeros((130, 200), np.uint8)
+    big[5:125, 20:180] = fr[2]
+    np.testing.assert_array_equal(H.calculate_optical_flow(big[5:125, 20:180], fr[3], levels=2), ref(fr[2], fr[3]))
+    assert _dropin_reuse_counts(H) == (h0 + 2, m0 + 1)
     # caller-provided flow buffer is filled and returned
     out = np.empty((120, 160, 2), np.float32)
     assert H.calculate_optical_flow(fr[0], fr[1], out, levels=2) is out
     np.testing.assert_array_equal(out, ref(fr[0], fr[1]))
+    # OPTFLOW_USE_INITIAL_FLOW: flow is in/out, the comparison comes before anything is overwritten
+    init = ref(fr[0], fr[1])
+    for prev_, next_ in ((fr[1], fr[2]), (fr[2], fr[3]), (fr[0], fr[4])):          # miss, hit, miss
+        io = init.copy()
+        got = H.calculate_optical_flow(prev_, next_, io, levels=2, flags=4)
+        np.testing.assert_array_equal(got, oracle.farneback(prev_, next_, levels=2, flags=4, init_flow=init, box_mode=oracle.BOX_BLOCKED))
+    H.close_cached_engines()
+
+
+def test_drop_in_notices_any_in_place_change(H, oracle):
+    """VERDICT r3 next #1.  The drop-in is a pure function of (prev, next): at 1080p, 200 single-byte edits of the frame the
+    device holds (anywhere -- rows that are no multiple of 16 included), a 15-row band rewritten in place and two 8-byte words
+    swapped inside one row must each be noticed; every call bit-exact against the oracle on the frames as they are at the call."""
+    H.close_cached_engines()
+    h, w, kw = 1080, 1920, dict(levels=3)
+    fr = video(3, h, w, 41)
+    bufs = [fr[1].copy(), fr[2].copy()]
+    H.calculate_optical_flow(fr[0], bufs[0], **kw)         # the device now holds bufs[0]
+    rng = np.random.default_rng(5)
+    edits = []
+    for i in range(200):
+        y = int(rng.integers(0, h))
+        if i % 4 != 0 and y % 16 == 0:
+            y += 1 + int(rng.integers(0, 15))              # three quarters of the edits in rows the old fingerprint never read
+        edits.append(("byte", min(y, h - 1), int(rng.integers(0, w)), int(rng.integers(1, 256))))
+    edits.append(("band",))
+    edits.append(("swap",))
+    nthreads = min(16, oracle.omp_max_threads())
+    pending = []
+
+    def check(pending):
+        frames = np.stack([f for p, n, _ in pending for f in (p, n)])
+        want = oracle.farneback_batch(frames, 0, nthreads=nthreads, box_mode=oracle.BOX_BLOCKED, **kw)
+        for k, (_, _, got) in enumerate(pending):
+            np.testing.assert_array_equal(got, want[k])
+
+    cur = 0
+    hits0, misses0 = _dropin_reuse_counts(H)
+    for e in edits:
+        held, other = bufs[cur], bufs[cur ^ 1]              # `held` was `next` of the previous call; edit it IN PLACE
+        if e[0] == "byte":
+            held[e[1], e[2]] ^= e[3]
+        elif e[0] == "band":
+            held[1:16] = 255 - held[1:16]
+        else:
+            row = held[16].view(np.uint64)
+            a, b = int(row[3]), int(row[100])
+            assert a != b
+            row[3], row[100] = b, a
+        got = H.calculate_optical_flow(held, other, **kw)
+        pending.append((held.copy(), other.copy(), got.copy()))
+        del got
+        cur ^= 1                                            # the device now holds `other`
+        if len(pending) == 16:
+            check(pending)
+            pending = []
+    if pending:
+        check(pending)
+    hits, misses = _dropin_reuse_counts(H)
+    assert (hits - hits0, misses - misses0) == (0, len(edits))    # every edit was noticed
+    # and an untouched frame is still reused
+    H.calculate_optical_flow(bufs[cur], bufs[cur ^ 1], **kw)
+    assert _dropin_reuse_counts(H) == (hits + 1, misses)
     H.close_cached_engines()
 
 
@@ -473,3 +556,119 @@ def test_pair_call_writes_a_pinned_flow_buffer_directly(H, oracle):
             eng.set_option("stream_zero_copy", 0)
             pinned[...] = -7
             np.testing.assert_array_equal(eng.calc(a, b, pinned), ref)
+
+
+def test_zero_copy_output_needs_the_whole_range_page_locked(H, oracle):
+    """VERDICT r3 next #6.  The GPU writes a flow buffer in place only when the page-locked allocation covers all of it: a pointer
+    64 bytes before the end of a page-locked block -- round 3 asked only "is the base pointer page-locked?" and would have let the
+    last kernel write 8wh bytes there -- must take the copy path.  The decision is checked first (ofarn_debug_mapped_host_range: no
+    kernel writes anywhere), then the call runs and must give the oracle's flow without touching the rest of the block."""
+    lib = H.load_library()
+    w, h, levels = 320, 240, 3
+    nbytes = w * h * 8
+    a, b, _ = translated_pair(h, w, 93, max_shift=4)
+    ref = oracle.farneback(a, b, levels=levels, box_mode=oracle.BOX_BLOCKED)
+    mapped = lambda addr, n: lib.ofarn_debug_mapped_host_range(C.c_void_p(addr), n)
+    # (1) a block from ofarn_host_alloc: its own extent decides
+    p = C.c_void_p()
+    assert lib.ofarn_host_alloc(nbytes, C.byref(p)) == 0
+    try:
+        assert mapped(p.value, nbytes) == 1
+        assert mapped(p.value, nbytes + 1) == 0
+        assert mapped(p.value + nbytes - 64, 64) == 1
+        assert mapped(p.value + nbytes - 64, nbytes) == 0
+        assert mapped(p.value + 8, nbytes) == 0
+    finally:
+        assert lib.ofarn_host_free(p) == 0
+    assert mapped(p.value, nbytes) == 0                     # freed: no longer in the registry, no longer page-locked
+    # (2) page-locked by someone else (a pinned torch tensor): the runtime's extent decides; the tail is never accepted
+    torch = pytest.importorskip("torch")
+    t = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    assert mapped(t.data_ptr() + nbytes - 64, nbytes) == 0
+    assert mapped(t.data_ptr(), nbytes) in (0, 1)           # 1 where hipMemGetAddressRange knows the block (profiles/r04_pinned_range.txt)
+    # (3) pageable memory
+    plain = np.empty(nbytes, np.uint8)
+    assert mapped(plain.ctypes.data, nbytes) == 0
+    # (4) end to end with a buffer in the MIDDLE of a larger page-locked block: covered -> written in place, and nothing in front of
+    # or behind it is touched (a partly covered buffer cannot be run safely by a test: it is refused by (1) before any kernel runs,
+    # and the copy path it then takes is the one test_pair_call_writes_a_pinned_flow_buffer_directly runs with the switch off)
+    big = H.pinned_empty((nbytes + 8192,), np.uint8)
+    big[...] = 0xA5
+    out = big[4096:4096 + nbytes].view(np.float32).reshape(h, w, 2)
+    with H.FarnebackEngine(w, h, 1, levels=levels) as eng:
+        assert mapped(out.ctypes.data, nbytes) == 1
+        assert mapped(out.ctypes.data, nbytes + 4096) == 1 and mapped(out.ctypes.data, nbytes + 4097) == 0
+        got = eng.calc(a, b, out)
+        assert got is out
+        np.testing.assert_array_equal(got, ref)
+        assert (big[:4096] == 0xA5).all() and (big[4096 + nbytes:] == 0xA5).all()
+        np.testing.assert_array_equal(eng.calc_reuse(a, b, out), ref)
+        assert (big[:4096] == 0xA5).all() and (big[4096 + nbytes:] == 0xA5).all()
+
+
+def test_entry_points_leave_the_callers_device_alone(H):
+    """VERDICT r3 next #6.  Every ofarn_* entry point runs on its context's device and restores the calling thread's current device
+    on return.  With a second GPU visible this is observed directly; on a one-GPU box the library is told that the caller was on
+    ordinal 5 (ofarn_debug_device_scope) and must report that it switched back to 5 after each call -- error returns included."""
+    lib = H.load_library()
+    torch = pytest.importorskip("torch")
+    w, h = 160, 120
+    a, b, _ = translated_pair(h, w, 7, max_shift=2)
+    scopes, restored = C.c_int(0), C.c_int(0)
+    if torch.cuda.device_count() >= 2:
+        torch.cuda.set_device(1)
+        with H.FarnebackEngine(w, h, 1, device=0, levels=2) as eng:
+            assert torch.cuda.current_device() == 1
+            eng.calc(a, b)
+            assert torch.cuda.current_device() == 1
+            eng.stream_next(a); eng.stream_next(b)
+            assert torch.cuda.current_device() == 1
+        assert torch.cuda.current_device() == 1
+        torch.cuda.set_device(0)
+        return
+    with H.FarnebackEngine(w, h, 1, device=0, levels=2) as eng:
+        lib.ofarn_debug_device_scope(5, C.byref(scopes), C.byref(restored))
+        try:
+            calls = [
+                ("calc", lambda: eng.calc(a, b)),
+                ("calc_reuse", lambda: eng.calc_reuse(a, b)),
+                ("stream_next", lambda: (eng.stream_next(a), eng.stream_next(b))),
+                ("calc_batch", lambda: eng.calc_batch(np.stack([a, b]))),
+                ("danger_map", lambda: eng.danger_map(np.zeros((h, w, 2), np.float32))),
+                ("bgr2gray", lambda: eng.bgr2gray(np.zeros((h, w, 3), np.uint8))),
+                ("reserve", lambda: eng.reserve(w, h, 1)),
+                ("bad size -> error return", lambda: pytest.raises(ValueError, eng.calc, np.zeros((h + 1000, w + 5000), np.uint8),
+                                                                   np.zeros((h + 1000, w + 5000), np.uint8))),
+            ]
+            for name, call in calls:
+                lib.ofarn_debug_device_scope(5, C.byref(scopes), C.byref(restored))     # clears "last restored"
+                n0 = scopes.value
+                call()
+                lib.ofarn_debug_device_scope(5, C.byref(scopes), C.byref(restored))
+                assert scopes.value > n0 or name.startswith("bad"), name
+                if scopes.value > n0:
+                    assert restored.value == 5, (name, restored.value)
+        finally:
+            lib.ofarn_debug_device_scope(-1, None, None)
+    assert torch.cuda.current_device() == 0
+
+
+def test_pinned_source_frame_may_be_rewritten_after_the_next_submit(H, oracle):
+    """a capture loop that reads every frame into ONE page-locked buffer.  ofarn_stream_submit uploads such a frame from
+    where it lies; the contract is that the buffer may be rewritten once the NEXT submit (or a wait) has returned -- the library
+    waits for the previous upload there.  Every flow must be the oracle's."""
+    w, h, kw = 320, 240, dict(levels=3)
+    fr = video(6, h, w, 53)
+    refs = [oracle.farneback(fr[i], fr[i + 1], box_mode=oracle.BOX_BLOCKED, **kw) for i in range(5)]
+    cap = [H.pinned_empty((h, w), np.uint8), H.pinned_empty((h, w), np.uint8)]          # two capture buffers used in turn
+    outs = [H.pinned_empty((h, w, 2)) for _ in range(5)]
+    with H.FarnebackEngine(w, h, 1, **kw) as eng:
+        for i in range(6):
+            buf = cap[i & 1]            # the buffer of turn i-2: the submit of turn i-1 has returned, so it is free again
+            buf[...] = fr[i]
+            eng.stream_submit(buf, outs[max(i - 1, 0)])          # the priming call ignores the flow buffer
+        eng.stream_wait()
+        cap[0][...] = 0
+        cap[1][...] = 0
+    for i in range(5):
+        np.testing.assert_array_equal(outs[i], refs[i])

@@ -250,34 +250,22 @@ def test_drawing_entry_points_reject_a_null_context():
         assert b"NULL" in lib.ofarn_last_error()
 
 
-def test_drop_in_frame_reuse_bookkeeping():
-    """The drop-in's reuse rule without a GPU: a slot "holds" a frame only if it is the SAME array object as the last call's `next`
-    and its fingerprint (address, shape, strides, checksum of every 16th row) is unchanged; an in-place change to a sampled row, a
-    copy, a view, a dead reference or a non-array are all "not held"."""
+def test_drop_in_slot_hint_bookkeeping():
+    """The drop-in keeps NO fingerprint of a frame any more (round 3's sampled checksum could miss an in-place edit): a slot only
+    remembers WHICH array object was `next` in its last call, as a hint for choosing among the contexts of a key; whether the held
+    frame equals `prev` is decided in the library by comparing every byte (ofarn_calc_reuse, tests/test_gpu_stream.py)."""
+    assert not hasattr(ofarn, "_frame_signature") and not hasattr(ofarn._Slot, "holds")
     slot = ofarn._Slot(eng=None)
     a = np.random.default_rng(0).integers(0, 256, (120, 160)).astype(np.uint8)
-    assert not slot.holds(a)
+    assert not slot.is_last(a)
     slot.remember(a)
-    assert slot.holds(a)
-    assert not slot.holds(a.copy()) and not slot.holds(a[:]) and not slot.holds(a.tolist())
-    a[16, 5] ^= 1                         # row 16 is sampled
-    assert not slot.holds(a)
-    a[16, 5] ^= 1
-    assert slot.holds(a)
-    odd = a[:, 1:]                        # rows that cannot be read as 64-bit words: byte sums
-    slot.remember(odd)
-    assert slot.holds(odd)
-    odd[32, 0] ^= 1
-    assert not slot.holds(odd)
-    odd[32, 0] ^= 1
-    slot.remember(a)
+    assert slot.is_last(a) and not slot.is_last(a.copy()) and not slot.is_last(a[:]) and not slot.is_last(a.tolist())
     b = a.copy()
     slot.remember(b)
-    assert slot.holds(b) and not slot.holds(a)
+    assert slot.is_last(b) and not slot.is_last(a)
     del b
     import gc
     gc.collect()
-    assert slot.last_ref() is None and not slot.holds(a)
+    assert slot.last_ref() is None and not slot.is_last(a)
     slot.remember([1, 2, 3])              # not weak-referenceable: forgotten
     assert slot.last_ref is None
-    assert ofarn._frame_signature(a) == ofarn._frame_signature(a) != ofarn._frame_signature(a.copy())

@@ -49,8 +49,24 @@ def main():
                 st.next(frames[i & 15])
             ms_s = 1e3 * (time.perf_counter() - t0) / a.frames
         ms_keep = loop(24, keep=True)
-        print(f"{a.w}x{a.h} levels={levels}: calculate_optical_flow loop {ms:.3f} ms/frame  (caller keeps every flow: {ms_keep:.3f})   "
-              f"FlowStream.next {ms_s:.3f} ms/frame", flush=True)
+        # the miss path: the caller edits the held frame in place before every call (one byte), so every call starts over
+        def loop_edited(n):
+            prev, s = frames[0].copy(), 0.0
+            for i in range(1, n + 1):
+                gray = frames[i & 15].copy()
+                prev[(7 * i) % a.h, (13 * i) % a.w] ^= 1
+                t0 = time.perf_counter()
+                H.calculate_optical_flow(prev, gray, levels=levels)
+                s += time.perf_counter() - t0
+                prev = gray
+            return 1e3 * s / n
+        ms_edit = loop_edited(a.frames)
+        from hackathonopticalflow_amd import ofarn
+        hm = [sl.eng.reuse_info() for e in ofarn._engines.values() for sl in e.slots if sl.eng is not None]
+        mode = "exact byte compare" if ofarn._DROPIN_REUSE else "OFARN_DROPIN_REUSE=0 (no frame held)"
+        print(f"{a.w}x{a.h} levels={levels} [{mode}]: dropin_loop_ms_per_frame {ms:.3f}  (caller keeps every flow: {ms_keep:.3f}; "
+              f"held frame edited in place before every call: {ms_edit:.3f})   FlowStream.next {ms_s:.3f} ms/frame   "
+              f"reuse (hits, misses) per context: {hm}", flush=True)
 
 
 if __name__ == "__main__":

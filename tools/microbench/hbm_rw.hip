@@ -91,14 +91,17 @@ __global__ __launch_bounds__(256) void k_copy_blk(const f4 *src, f4 *dst, size_t
 // (interleaved layout).
 // OUTW: output columns per block (246 = 256 threads minus the 2 x 5 halo lanes of the round-1 kernel; 240 and 224 make a block's
 // row segment a whole number of 128-byte lines in the 16-B plane, resp. in both planes)
-template <int MODE, int OUTW = 246>
-__global__ __launch_bounds__(256) void k_march_write(float4 *p4, float *p1, int W, int H, int strip, float v)
+// Round 4: 192 and 256 columns per block -- the two widths below / above 240 for which a block's row segment
+// is a whole number of 128-byte lines in BOTH planes (192: 3072 + 768 B, 256: 4096 + 1024 B; 240 ends the 4-B plane on a half line:
+// 960 B = 7.5 lines).  THREADS: block size (272 = 256 writers + 2 x 8 halo lanes); HALO: idle lanes in front of the writers.
+template <int MODE, int OUTW = 246, int THREADS = 256, int HALO = 5>
+__global__ __launch_bounds__(THREADS) void k_march_write(float4 *p4, float *p1, int W, int H, int strip, float v)
 {
-    const int x = blockIdx.x * OUTW + threadIdx.x - 5;
+    const int x = blockIdx.x * OUTW + threadIdx.x - HALO;
     const int y0 = blockIdx.y * strip, y1 = min(y0 + strip, H);
     const size_t f = (size_t)blockIdx.z * W * H;
-    if (threadIdx.x < 5 || threadIdx.x >= 5 + OUTW || x >= W) return;
-    const int lx = threadIdx.x - 5;
+    if ((int)threadIdx.x < HALO || (int)threadIdx.x >= HALO + OUTW || x >= W || x < 0) return;
+    const int lx = threadIdx.x - HALO;
     for (int y = y0; y < y1; y++) {
         size_t o = f + (size_t)y * W + x;
         if (MODE == 2) o = f + ((size_t)blockIdx.x * H + y) * 246 + lx;
@@ -173,6 +176,25 @@ int main(int argc, char **argv)
         time(name, gb20, [&] { hipLaunchKernelGGL((k_march_write<0, 240>), dim3((W + 239) / 240, strips, F), dim3(256), 0, 0, b4, p1, W, H, sh, 1.f); });
         snprintf(name, sizeof name, "march write 16+4 B row-major, 224 columns per block, %d strips", strips);
         time(name, gb20, [&] { hipLaunchKernelGGL((k_march_write<0, 224>), dim3((W + 223) / 224, strips, F), dim3(256), 0, 0, b4, p1, W, H, sh, 1.f); });
+        // round 4: whole lines in both planes
+        snprintf(name, sizeof name, "march write 16+4 B row-major, 192 columns per block, %d strips", strips);
+        time(name, gb20, [&] { hipLaunchKernelGGL((k_march_write<0, 192>), dim3((W + 191) / 192, strips, F), dim3(256), 0, 0, b4, p1, W, H, sh, 1.f); });
+        snprintf(name, sizeof name, "march write 16+4 B row-major, 256 columns per 272-thread block, %d strips", strips);
+        time(name, gb20, [&] { hipLaunchKernelGGL((k_march_write<0, 256, 272, 8>), dim3((W + 255) / 256, strips, F), dim3(272), 0, 0, b4, p1, W, H, sh, 1.f); });
+        snprintf(name, sizeof name, "march write 16+4 B row-major, 128 columns per 192-thread block, %d strips", strips);
+        time(name, gb20, [&] { hipLaunchKernelGGL((k_march_write<0, 128, 192, 32>), dim3((W + 127) / 128, strips, F), dim3(192), 0, 0, b4, p1, W, H, sh, 1.f); });
+        snprintf(name, sizeof name, "march write 16+4 B row-major, 320 columns per 384-thread block, %d strips", strips);
+        time(name, gb20, [&] { hipLaunchKernelGGL((k_march_write<0, 320, 384, 5>), dim3((W + 319) / 320, strips, F), dim3(384), 0, 0, b4, p1, W, H, sh, 1.f); });
+        snprintf(name, sizeof name, "march write 16+4 B row-major, 480 columns per 512-thread block, %d strips", strips);
+        time(name, gb20, [&] { hipLaunchKernelGGL((k_march_write<0, 480, 512, 5>), dim3((W + 479) / 480, strips, F), dim3(512), 0, 0, b4, p1, W, H, sh, 1.f); });
+        snprintf(name, sizeof name, "march write 16+4 B row-major, 960 columns per 1024-thread block, %d strips", strips);
+        time(name, gb20, [&] { hipLaunchKernelGGL((k_march_write<0, 960, 1024, 5>), dim3((W + 959) / 960, strips, F), dim3(1024), 0, 0, b4, p1, W, H, sh, 1.f); });
+        snprintf(name, sizeof name, "march write 16+4 B row-major nt, 240 columns per block, %d strips", strips);
+        time(name, gb20, [&] { hipLaunchKernelGGL((k_march_write<3, 240>), dim3((W + 239) / 240, strips, F), dim3(256), 0, 0, b4, p1, W, H, sh, 1.f); });
+        snprintf(name, sizeof name, "march write 16+4 B row-major nt, 192 columns per block, %d strips", strips);
+        time(name, gb20, [&] { hipLaunchKernelGGL((k_march_write<3, 192>), dim3((W + 191) / 192, strips, F), dim3(256), 0, 0, b4, p1, W, H, sh, 1.f); });
+        snprintf(name, sizeof name, "march write 16+4 B row-major nt, 256 columns per 272-thread block, %d strips", strips);
+        time(name, gb20, [&] { hipLaunchKernelGGL((k_march_write<3, 256, 272, 8>), dim3((W + 255) / 256, strips, F), dim3(272), 0, 0, b4, p1, W, H, sh, 1.f); });
         snprintf(name, sizeof name, "march write 16 B plane only, %d strips", strips);
         time(name, gb16, [&] { hipLaunchKernelGGL(k_march_write<1>, grid, dim3(256), 0, 0, b4, p1, W, H, sh, 1.f); });
         snprintf(name, sizeof name, "march write 16+4 B column-tiled, %d strips", strips);
