@@ -156,17 +156,6 @@ int ofarn_stream_next_device_bgr(ofarn_ctx *ctx, const uint8_t *d_bgr, int w, in
 int ofarn_stream_next_view(ofarn_ctx *ctx, const uint8_t *h_frame, int bgr, int w, int h, int stride, uint8_t *h_mask,
                            uint8_t *h_v, int arrow_step, int32_t *h_lines, uint8_t *h_rainbow);
 int ofarn_stream_view_flow(ofarn_ctx *ctx, int w, int h, float *h_flow);
-/* The viewer's obstacle layer of that turn (draw_sparse_lamps, see ofarn_draw_lamps below) from the danger map the turn left on the
- * device: h_out uint8[h][w][3] BGR.  over_frame != 0: the layer added onto the turn's own BGR frame -- output_bgr =
- * cv2.add(output_bgr, draw_sparse_lamps(...)), pathfinder_viewer.py:299-300 -- which the turn had uploaded anyway (needs bgr != 0
- * and h_mask / h_v in that ofarn_stream_next_view call). */
-int ofarn_stream_view_lamps(ofarn_ctx *ctx, int w, int h, int radius, int over_frame, uint8_t *h_out);
-/* draw_hsv of that turn's flow (which stayed on the device), BGR uint8[h][w][3]; over_frame != 0: added onto the turn's BGR frame,
- * output_bgr = cv2.add(output_bgr, draw_hsv(flow)) (DenseOF.py:577-578). */
-int ofarn_stream_view_rainbow(ofarn_ctx *ctx, int w, int h, int over_frame, uint8_t *h_out);
-/* draw_flow's image for that turn's flow (ofarn_draw_flow below): the arrow layer, or with over_frame != 0 the turn's BGR frame with
- * the layer added -- output_bgr = cv2.add(output_bgr, draw_flow(shape, flow)) (DenseOF.py:574). */
-int ofarn_stream_view_arrows(ofarn_ctx *ctx, int w, int h, int step, int over_frame, uint8_t *h_out);
 /* Pipelined form for throughput: ofarn_stream_submit enqueues the turn (upload, kernels, transfer of the flow into h_flow on a copy
  * stream) and returns without waiting; the caller submits the next frame at once, whose kernels then run BESIDE this turn's
  * device-to-host transfer (at 1080p the 16.6 MB of flow take about as long over PCIe as the kernels).  h_flow of a turn is complete
@@ -179,6 +168,15 @@ int ofarn_stream_view_arrows(ofarn_ctx *ctx, int w, int h, int step, int over_fr
  * OPTFLOW_USE_INITIAL_FLOW (OFARN_E_UNSUPPORTED). */
 int ofarn_stream_submit(ofarn_ctx *ctx, const uint8_t *h_gray, int w, int h, int stride, float *h_flow);
 int ofarn_stream_wait(ofarn_ctx *ctx, int leave_in_flight);
+/* EXPERIMENT, off by default (ofarn_set_option "coop_levels": 0 = default; 1 = the levels whose tiles are all resident on the chip
+ * at once; 2 = every level that takes the tile kernel; OFARN_COOP_LEVELS when the context is created).  A synchronous turn
+ * (ofarn_stream_next*, ofarn_stream_next_view, ofarn_calc_reuse) then runs every iteration of the coarse levels of the pair --
+ * twelve launches of a few microseconds each at 1080p / levels 5 -- in ONE launch behind a device-wide barrier whose waits are
+ * bounded.  Bit-identical, and measured 40-50 us SLOWER per 1080p turn than the separate launches (a device-wide barrier costs as
+ * much as a kernel boundary on this part), which is why it is off.  If a wait ever gives up (a grid that is not fully resident on a
+ * shared GPU), the call reruns the iterations with separate launches before it returns and the context stops using the cooperative
+ * launch.  *launches / *fallbacks count both. */
+int ofarn_coop_info(const ofarn_ctx *ctx, unsigned long long *launches, unsigned long long *fallbacks);
 /* Forgets the held frame: the next call primes again (a cut in the video, a seek: DenseOF.py:476-481 re-reads prev_gray). */
 int ofarn_stream_reset(ofarn_ctx *ctx);
 /* 1 if the session holds a frame of this size (the next ofarn_stream_next* call will produce a flow), else 0. */
@@ -220,30 +218,6 @@ int ofarn_flow_arrows(ofarn_ctx *ctx, const float *h_flow, int n, int w, int h, 
 int ofarn_flow_arrows_device(ofarn_ctx *ctx, const float *d_flow, int n, int w, int h, int step,
                              int32_t *d_lines, void *hip_stream);
 
-/* draw_flow as the reference returns it (DenseOF.py:40-59, pathfinder_viewer.py:51-73): the BGR layer uint8[n][h][w][3] with the
- * lines of ofarn_flow_arrows drawn by cv2.polylines(img, lines, False, (0, 255, 0)) -- thickness 1, LINE_8: drawing.cpp clipLine +
- * LineIterator -- and cv2.circle(img, (x1, y1), 1, (0, 255, 0), -1) at every start point.  base (uint8[n][h][w][3] or NULL):
- * cv2.add(base, layer) instead of the layer (DenseOF.py:574); d_base may equal d_out. */
-int ofarn_draw_flow(ofarn_ctx *ctx, const float *h_flow, int n, int w, int h, int step, const uint8_t *h_base, uint8_t *h_out);
-int ofarn_draw_flow_device(ofarn_ctx *ctx, const float *d_flow, int n, int w, int h, int step, const uint8_t *d_base, uint8_t *d_out,
-                           void *hip_stream);
-
-/* cv2.add on uint8 images, n bytes: out = saturate(a + b) -- how the viewers stack their layers onto the frame
- * (DenseOF.py:574-582, pathfinder_viewer.py:297-300).  out may be a or b. */
-int ofarn_add_u8(ofarn_ctx *ctx, const uint8_t *h_a, const uint8_t *h_b, size_t n, uint8_t *h_out);
-int ofarn_add_u8_device(ofarn_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, size_t n, uint8_t *d_out, void *hip_stream);
-
-/* draw_sparse_lamps (pathfinder_viewer.py:196-222) for danger maps on the context's measurement grid: a BGR layer uint8[n][h][w][3]
- * that is black except for one filled disc per danger point (mask != 0) -- hsv[y, x] = (0, 255, V), cv2.cvtColor(HSV2BGR) = (0, 0, V),
- * cv2.circle(bgr, (x, y), radius, that colour, thickness=-1) in drawing.cpp's LINE_8 raster; the reference's radius is 6.  mask, v:
- * uint8[n][P] as ofarn_calc_batch / ofarn_grid_filter return them.  base (uint8[n][h][w][3], or NULL): the layer is added onto it
- * with saturation, cv2.add(output_bgr, layer) of pathfinder_viewer.py:299-300.  The grid step must exceed 2 * radius (discs that
- * touch would take the colour under their centre: OFARN_E_UNSUPPORTED); radius 0..31. */
-int ofarn_draw_lamps(ofarn_ctx *ctx, const uint8_t *h_mask, const uint8_t *h_v, int n, int w, int h, int radius,
-                     const uint8_t *h_base, uint8_t *h_out);
-int ofarn_draw_lamps_device(ofarn_ctx *ctx, const uint8_t *d_mask, const uint8_t *d_v, int n, int w, int h, int radius,
-                            const uint8_t *d_base, uint8_t *d_out, void *hip_stream);
-
 /* ---- sparse pyramidal Lucas-Kanade -----------------------------------------
  * cv2.calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts, winSize, maxLevel, criteria, flags,
  * minEigThreshold) as pathfinder_viewer.py:153-158, DenseOF.py:181-185 and SparseOF.py:35-36 call it
@@ -280,14 +254,6 @@ int ofarn_vector_filter(ofarn_ctx *ctx, const float *h_vecs, int n, int w, int h
                         uint8_t *h_v, int32_t *h_iflow);
 int ofarn_vector_filter_device(ofarn_ctx *ctx, const float *d_vecs, int n, int w, int h, uint8_t *d_mask,
                                uint8_t *d_v, int32_t *d_iflow, void *hip_stream);
-/* The frame layer get_flow_lk returns (pathfinder_viewer.py:147, 180-192): BGR uint8[n][h][w][3], black but for the kept vectors --
- * cv2.polylines(layer, lines, False, (0, 0, 255)) from each kept grid point to point + iflow, then cv2.circle(layer, point, 1,
- * (255, 0, 255), 1) -- and, with draw_bad != 0 (the viewer's key 4), the rejected ones after them in (255, 255, 0).  iflow, mask:
- * what ofarn_vector_filter / ofarn_grid_filter return (iflow is defined at every grid point).  Stack it onto the frame with ofarn_add_u8. */
-int ofarn_draw_vectors(ofarn_ctx *ctx, const int32_t *h_iflow, const uint8_t *h_mask, int n, int w, int h, int draw_bad, uint8_t *h_out);
-int ofarn_draw_vectors_device(ofarn_ctx *ctx, const int32_t *d_iflow, const uint8_t *d_mask, int n, int w, int h, int draw_bad,
-                              uint8_t *d_out, void *hip_stream);
-
 /* ---- multi-GPU in one process -------------------------------------------------------
  * The reference processes one pair per loop turn with no state beyond prev_gray (DenseOF.py:519-525), so pairs are independent
  * units: device g of G owns the contiguous range ofarn_shard_pairs(n_pairs, g, G) and there is no data-path collective.  One
@@ -422,6 +388,56 @@ int ofarn_stage_scharr(ofarn_ctx *ctx, const uint8_t *h_img, int w, int h, int16
 /* resize(flow, INTER_AREA) * mul, shrinking only (the coarsest-level start of USE_INITIAL_FLOW) */
 int ofarn_stage_resize_area(ofarn_ctx *ctx, const float *h_flow, int sw, int sh, int dw, int dh, float mul,
                             float *h_out);
+
+/* ==== EXTRAS, NOT PART OF THE SURVEY 8 CONTRACT ===========================================================================
+ * Pixel rendering of the viewers' GUI layers (cv2.polylines / cv2.circle / cv2.add rasters).  SURVEY 2 rows 6, 7, 10 and 12 mark
+ * these OUT OF SCOPE (GUI); SURVEY 8(f) rank 3 asks only for the HSV wheel and the arrow SAMPLING above.  They were built in round 3,
+ * are tested (tests/test_gpu_parity.py, bit-exact against restated cv2 rasters: "parity unpinned" like the rest) and are FROZEN: no
+ * further work goes here.  Nothing in the rows of SURVEY 8 depends on them. */
+/* -- layers of a view turn (ofarn_stream_next_view) rendered on the device -- */
+/* The viewer's obstacle layer of that turn (draw_sparse_lamps, see ofarn_draw_lamps below) from the danger map the turn left on the
+ * device: h_out uint8[h][w][3] BGR.  over_frame != 0: the layer added onto the turn's own BGR frame -- output_bgr =
+ * cv2.add(output_bgr, draw_sparse_lamps(...)), pathfinder_viewer.py:299-300 -- which the turn had uploaded anyway (needs bgr != 0
+ * and h_mask / h_v in that ofarn_stream_next_view call). */
+int ofarn_stream_view_lamps(ofarn_ctx *ctx, int w, int h, int radius, int over_frame, uint8_t *h_out);
+/* draw_hsv of that turn's flow (which stayed on the device), BGR uint8[h][w][3]; over_frame != 0: added onto the turn's BGR frame,
+ * output_bgr = cv2.add(output_bgr, draw_hsv(flow)) (DenseOF.py:577-578). */
+int ofarn_stream_view_rainbow(ofarn_ctx *ctx, int w, int h, int over_frame, uint8_t *h_out);
+/* draw_flow's image for that turn's flow (ofarn_draw_flow below): the arrow layer, or with over_frame != 0 the turn's BGR frame with
+ * the layer added -- output_bgr = cv2.add(output_bgr, draw_flow(shape, flow)) (DenseOF.py:574). */
+int ofarn_stream_view_arrows(ofarn_ctx *ctx, int w, int h, int step, int over_frame, uint8_t *h_out);
+
+/* draw_flow as the reference returns it (DenseOF.py:40-59, pathfinder_viewer.py:51-73): the BGR layer uint8[n][h][w][3] with the
+ * lines of ofarn_flow_arrows drawn by cv2.polylines(img, lines, False, (0, 255, 0)) -- thickness 1, LINE_8: drawing.cpp clipLine +
+ * LineIterator -- and cv2.circle(img, (x1, y1), 1, (0, 255, 0), -1) at every start point.  base (uint8[n][h][w][3] or NULL):
+ * cv2.add(base, layer) instead of the layer (DenseOF.py:574); d_base may equal d_out. */
+int ofarn_draw_flow(ofarn_ctx *ctx, const float *h_flow, int n, int w, int h, int step, const uint8_t *h_base, uint8_t *h_out);
+int ofarn_draw_flow_device(ofarn_ctx *ctx, const float *d_flow, int n, int w, int h, int step, const uint8_t *d_base, uint8_t *d_out,
+                           void *hip_stream);
+
+/* cv2.add on uint8 images, n bytes: out = saturate(a + b) -- how the viewers stack their layers onto the frame
+ * (DenseOF.py:574-582, pathfinder_viewer.py:297-300).  out may be a or b. */
+int ofarn_add_u8(ofarn_ctx *ctx, const uint8_t *h_a, const uint8_t *h_b, size_t n, uint8_t *h_out);
+int ofarn_add_u8_device(ofarn_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, size_t n, uint8_t *d_out, void *hip_stream);
+
+/* draw_sparse_lamps (pathfinder_viewer.py:196-222) for danger maps on the context's measurement grid: a BGR layer uint8[n][h][w][3]
+ * that is black except for one filled disc per danger point (mask != 0) -- hsv[y, x] = (0, 255, V), cv2.cvtColor(HSV2BGR) = (0, 0, V),
+ * cv2.circle(bgr, (x, y), radius, that colour, thickness=-1) in drawing.cpp's LINE_8 raster; the reference's radius is 6.  mask, v:
+ * uint8[n][P] as ofarn_calc_batch / ofarn_grid_filter return them.  base (uint8[n][h][w][3], or NULL): the layer is added onto it
+ * with saturation, cv2.add(output_bgr, layer) of pathfinder_viewer.py:299-300.  The grid step must exceed 2 * radius (discs that
+ * touch would take the colour under their centre: OFARN_E_UNSUPPORTED); radius 0..31. */
+int ofarn_draw_lamps(ofarn_ctx *ctx, const uint8_t *h_mask, const uint8_t *h_v, int n, int w, int h, int radius,
+                     const uint8_t *h_base, uint8_t *h_out);
+int ofarn_draw_lamps_device(ofarn_ctx *ctx, const uint8_t *d_mask, const uint8_t *d_v, int n, int w, int h, int radius,
+                            const uint8_t *d_base, uint8_t *d_out, void *hip_stream);
+
+/* The frame layer get_flow_lk returns (pathfinder_viewer.py:147, 180-192): BGR uint8[n][h][w][3], black but for the kept vectors --
+ * cv2.polylines(layer, lines, False, (0, 0, 255)) from each kept grid point to point + iflow, then cv2.circle(layer, point, 1,
+ * (255, 0, 255), 1) -- and, with draw_bad != 0 (the viewer's key 4), the rejected ones after them in (255, 255, 0).  iflow, mask:
+ * what ofarn_vector_filter / ofarn_grid_filter return (iflow is defined at every grid point).  Stack it onto the frame with ofarn_add_u8. */
+int ofarn_draw_vectors(ofarn_ctx *ctx, const int32_t *h_iflow, const uint8_t *h_mask, int n, int w, int h, int draw_bad, uint8_t *h_out);
+int ofarn_draw_vectors_device(ofarn_ctx *ctx, const int32_t *d_iflow, const uint8_t *d_mask, int n, int w, int h, int draw_bad,
+                              uint8_t *d_out, void *hip_stream);
 
 #ifdef __cplusplus
 }
