@@ -940,6 +940,7 @@ int ofarn_set_option(ofarn_ctx *c, const char *name, int value)
     else if (n == "stream_overlap") c->stream_overlap = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "push_blocks") c->push_blocks = value < 0 ? 0 : value;
     else if (n == "debug_fail_wave") c->debug_fail_wave = value;
+    else if (n == "prof_dual") c->prof_dual = value != 0;
     else if (n == "coop_levels") c->coop_levels = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "debug_coop_fail") {       // test hook: as if a wait had given up (the flag the blocks poll + the one the host reads)
         if (c->coop_fail && c->coop_bar) {
@@ -1109,7 +1110,7 @@ int calc_batch_device_impl(ofarn_ctx *c, const uint8_t *d_frames, bool bgr, int 
     // More than one wave: alternate them over two internal streams (each with its own workspace), forked
     // from and joined back into the caller's stream with events.  Per-kernel profiling keeps one stream.  (During capture
     // only if the second workspace already exists.)
-    const bool dual = c->dual && nwaves > 1 && !c->prof_on && (!capturing || (c->ws[1].R && (!bgr || c->gray[1]))) &&
+    const bool dual = c->dual && nwaves > 1 && (!c->prof_on || c->prof_dual) && (!capturing || (c->ws[1].R && (!bgr || c->gray[1]))) &&
                       alloc_workspace(c, 1) == 0 && (!bgr || ensure_gray(c, 1) == 0);
     if (dual) {
         HIP_TRY(hipEventRecord(c->ev_fork, s));

@@ -217,6 +217,8 @@ struct ofarn_ctx {
     // per-kernel profiling (ofarn_profile_*): hipEvent pairs around each launch, on the launch stream
     struct ProfRec { int stage, level; double units; hipEvent_t a, b; };
     bool prof_on = false;
+    bool prof_dual = false;       // "prof_dual": per-kernel timing does NOT force the waves of a batch onto one stream (each launch is
+                                  // bracketed on the stream it runs on; durations then include what co-running kernels take from it)
     bool force_generic = false;   // OFARN_FORCE_GENERIC=1 or ofarn_set_option: use the unfused kernels only
     int debug_fail_wave = -1;     // test hook: the (n+1)-th wave from now returns OFARN_E_NOMEM (error-path tests); -1 = off
     int tile_mode = -1;           // fused iteration: -1 = tile kernel for small grids, marching kernel otherwise; 0 / 1 = never / always

@@ -185,6 +185,10 @@ int main(int argc, char **argv)
         time(name, gb20, [&] { hipLaunchKernelGGL((k_march_write<0, 128, 192, 32>), dim3((W + 127) / 128, strips, F), dim3(192), 0, 0, b4, p1, W, H, sh, 1.f); });
         snprintf(name, sizeof name, "march write 16+4 B row-major, 320 columns per 384-thread block, %d strips", strips);
         time(name, gb20, [&] { hipLaunchKernelGGL((k_march_write<0, 320, 384, 5>), dim3((W + 319) / 320, strips, F), dim3(384), 0, 0, b4, p1, W, H, sh, 1.f); });
+        snprintf(name, sizeof name, "march write 16+4 B row-major, 384 columns per 448-thread block, %d strips", strips);
+        time(name, gb20, [&] { hipLaunchKernelGGL((k_march_write<0, 384, 448, 5>), dim3((W + 383) / 384, strips, F), dim3(448), 0, 0, b4, p1, W, H, sh, 1.f); });
+        snprintf(name, sizeof name, "march write 16+4 B row-major, 96 columns per 128-thread block, %d strips", strips);
+        time(name, gb20, [&] { hipLaunchKernelGGL((k_march_write<0, 96, 128, 5>), dim3((W + 95) / 96, strips, F), dim3(128), 0, 0, b4, p1, W, H, sh, 1.f); });
         snprintf(name, sizeof name, "march write 16+4 B row-major, 480 columns per 512-thread block, %d strips", strips);
         time(name, gb20, [&] { hipLaunchKernelGGL((k_march_write<0, 480, 512, 5>), dim3((W + 479) / 480, strips, F), dim3(512), 0, 0, b4, p1, W, H, sh, 1.f); });
         snprintf(name, sizeof name, "march write 16+4 B row-major, 960 columns per 1024-thread block, %d strips", strips);
