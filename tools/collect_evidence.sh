@@ -25,5 +25,9 @@ run bench_config4_1gpu.json python3 bench.py --config 4 --steps 5 --warmup 2 --c
 run bench_config5_1gpu.json python3 bench.py --config 5 --steps 5 --warmup 2 --cpu-sample 0 --no-family-check
 run bench_config4_rccl_ws1.json python3 bench.py --config 4 --gpus 1 --backend nccl --force-dist --steps 5 --warmup 2 --cpu-sample 0 --no-family-check
 run bench_config5_rccl_ws1.json python3 bench.py --config 5 --gpus 1 --backend nccl --force-dist --steps 5 --warmup 2 --cpu-sample 0 --no-family-check
+run bench_inproc_config3.json python3 bench.py --multi inproc --gpus 1 --config 3 --steps 5 --warmup 2 --no-family-check
+run bench_inproc_config4.json python3 bench.py --multi inproc --gpus 1 --config 4 --steps 5 --warmup 2 --cpu-sample 0
+run bench_inproc_config5.json python3 bench.py --multi inproc --gpus 1 --config 5 --steps 5 --warmup 2 --cpu-sample 0
+run bench_ranks_config3_same_box.json python3 bench.py --config 3 --steps 5 --warmup 2 --cpu-sample 0 --no-family-check --no-two-stream
 (cd tools/microbench && for b in hbm_rw march_layout valu_rates; do [ -x ./$b ] && { echo "\$ ./$b"; timeout -k 10 200 ./$b; } > ../../$OUT/$b.txt 2>&1; done)
 ls -la $OUT
