@@ -732,3 +732,47 @@ def test_cooperative_launch_that_gives_up_is_redone_with_separate_launches(H, or
         eng.set_option("coop_levels", 1)                        # a caller may switch it back on
         np.testing.assert_array_equal(eng.calc_reuse(fr[0], fr[1]), refs[0])
         assert eng.coop_info()[0] > 2
+
+
+def test_calc_reuse_random_call_sequences(H):
+    """ofarn_calc_reuse is a pure function of (prev, next) whatever happened on the context before: 120 random calls -- the loop's
+    pattern (prev = last next), repeats, copies, in-place edits of the held frame, unrelated pairs, strided views, other entry points
+    moving the session in between, a change of frame size and back -- each compared with the stateless pair call (ofarn_calc, which
+    the parity tests hold to the oracle) on a second context.  Hits and misses must both occur."""
+    rng = np.random.default_rng(77)
+    sizes = [(160, 120), (200, 152)]
+    vids = {s: [f.copy() for f in video(7, s[1], s[0], 70 + i)] for i, s in enumerate(sizes)}
+    kw = dict(levels=2)
+    with H.FarnebackEngine(200, 152, 1, **kw) as eng, H.FarnebackEngine(200, 152, 1, **kw) as ref:
+        size = sizes[0]
+        last_next = None
+        for step in range(120):
+            r = rng.random()
+            if r < 0.08:
+                size = sizes[int(rng.integers(0, 2))]
+            fr = vids[size]
+            w, h = size
+            kind = rng.random()
+            nxt = fr[int(rng.integers(0, len(fr)))]
+            if last_next is not None and last_next.shape == (h, w) and kind < 0.45:
+                prev = last_next                                   # the loop's pattern
+            elif last_next is not None and last_next.shape == (h, w) and kind < 0.55:
+                prev = last_next.copy()                            # same bytes, another object
+            elif last_next is not None and last_next.shape == (h, w) and kind < 0.70:
+                prev = last_next
+                prev[int(rng.integers(0, h)), int(rng.integers(0, w))] ^= int(rng.integers(1, 256))    # edited in place
+            elif kind < 0.80:
+                big = np.zeros((h + 9, w + 13), np.uint8)          # a strided view
+                big[4:4 + h, 6:6 + w] = fr[int(rng.integers(0, len(fr)))]
+                prev = big[4:4 + h, 6:6 + w]
+            else:
+                prev = fr[int(rng.integers(0, len(fr)))]
+            if rng.random() < 0.15:
+                eng.stream_next(fr[int(rng.integers(0, len(fr)))])   # another entry point moves the session
+            if rng.random() < 0.05:
+                eng.stream_reset()
+            got = eng.calc_reuse(prev, nxt)
+            np.testing.assert_array_equal(got, ref.calc(np.ascontiguousarray(prev), np.ascontiguousarray(nxt)), err_msg=f"step {step}")
+            last_next = nxt
+        hits, misses = eng.reuse_info()
+        assert hits >= 20 and misses >= 20 and hits + misses == 120, (hits, misses)
