@@ -234,6 +234,29 @@ def parity_report(ofa, gpu_flow, gpu_mask, ref, gt, W, H, family):
     return out
 
 
+def literal_order_leg(ofa, torch, frames_dev, ref, n, W, H, params, device_index):
+    """After the timed region (never `value`): the first n pairs again with "box_order" = 1 -- the box window summed in optflowgf.cpp's
+    literal order (k_vsum_running + k_hsum_running_solve) -- compared with the CPU oracle in the same order: bit-exact or not, and
+    what the mode costs.  The throughput kernels use restarted sums (the EPE above is between the two orders)."""
+    with ofa.FarnebackEngine(W, H, n, device_index, **params) as lit:
+        lit.set_option("box_order", 1)
+        flow = torch.empty((n, H, W, 2), dtype=torch.float32, device=frames_dev.device)
+        st = torch.cuda.current_stream().cuda_stream
+        run = lambda: lit.calc_batch_device(frames_dev[:2 * n], 2 * n, W, H, ofa.PAIRS_INDEPENDENT, flow, None, None, stream=st)
+        run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        got = flow.cpu().numpy()
+    diff = np.abs(got.astype(np.float64) - ref[:n].astype(np.float64))
+    return {"pairs": n, "bit_exact_vs_cpu_oracle_in_opencvs_order": bool(np.array_equal(got, ref[:n])), "max_abs_diff_px": float(diff.max()),
+            "pairs_per_s": round(n / dt, 2),
+            "note": "ofarn_set_option \"box_order\" = 1: FarnebackUpdateFlow_Blur's own running sums (one per column down the image with "
+                    "float row differences, one along each row); unfused, a verification mode"}
+
+
 def opencv_column(frames_np, gpu_flow, params, n):
     """EPE and pairs/s against the REAL cv2.calcOpticalFlowFarneback, only if cv2 is importable on this box."""
     try:
@@ -892,6 +915,7 @@ def main():
         par = parity_report(ofa, flow[:npar].cpu().numpy(), mask[:npar].cpu().numpy(), ref[:npar],
                             [gt_u[i] for i in range(npar)], W, H, args.family)
         par["opencv"] = opencv_column(fr_np, flow[:min(npar, 4)].cpu().numpy(), params, min(npar, 4))
+        par["literal_order_mode"] = literal_order_leg(ofa, torch, fr_u, ref, min(npar, 8), W, H, params, dev_index)
         out["parity"] = par
         out["mean_epe_vs_cpu_oracle_px"] = par["epe_vs_cpu_oracle"]["mean"]
         out[f"speedup_vs_cpu_{cb['cores']}_threads"] = round(value / cb["value"], 1)

@@ -300,6 +300,63 @@ __global__ __launch_bounds__(256) void k_blur_solve(const float *__restrict__ M,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stage D in OpenCV's LITERAL summation order (ofarn_set_option "box_order" = 1; oracle OFO_BOX_RUNNING).  optflowgf.cpp's
+// FarnebackUpdateFlow_Blur keeps ONE double running sum per column-channel down the whole image, updated with the FLOAT difference
+// of the entering and the leaving row, and ONE double running sum along each row.  A value therefore depends on every row above
+// it and every column left of it in that order: no strip or tile can be started in the middle, which is why the throughput kernels
+// use restarted sums (OFO_BOX_BLOCKED, within 3e-5 px of this).  Reproduced here as it is, with the parallelism the order leaves:
+//   k_vsum_running:       a thread per (column, channel) marches down ALL rows:  V[c][y][x] = vsum after row y's update (double)
+//   k_hsum_running_solve: a thread per row marches along ALL columns:           g += V[x+m] - V[x-m-1], solve, store
+// 80 B per pixel of extra HBM traffic and two sequential chains: a verification mode (3-4 x slower), not the default.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_vsum_running(const float *__restrict__ M, double *__restrict__ V, int w, int h, int m)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= w) return;
+    const size_t npx = (size_t)w * h;
+    const size_t plane = ((size_t)blockIdx.z * 5 + blockIdx.y) * npx;
+    const float *src = M + plane + x;
+    double *dst = V + plane + x;
+    auto row = [&](int y) { return src[(size_t)y * w]; };
+    double vsum = (double)(row(0) * (float)(m + 2));                   // vsum[x] = srow0[x] * (m + 2): a float product
+    for (int y = 1; y < m; y++) vsum += (double)row(y < h - 1 ? y : h - 1);
+    for (int y = 0; y < h; y++) {
+        const float s0 = row(y - m - 1 > 0 ? y - m - 1 : 0), s1 = row(y + m < h - 1 ? y + m : h - 1);
+        vsum += (double)(s1 - s0);                                      // the row difference is rounded to float first
+        dst[(size_t)y * w] = vsum;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_hsum_running_solve(const double *__restrict__ V, float2 *__restrict__ flow, int w, int h, int m,
+                                                          double scale)
+{
+    const int y = blockIdx.x * 64 + threadIdx.x;
+    if (y >= h) return;
+    const size_t npx = (size_t)w * h;
+    const double *v[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) v[c] = V + ((size_t)blockIdx.y * 5 + c) * npx + (size_t)y * w;
+    auto at = [&](int c, int x) { return v[c][x < 0 ? 0 : (x > w - 1 ? w - 1 : x)]; };     // the replicated borders of vsum[]
+    double g[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        g[c] = at(c, 0) * (m + 2);
+        for (int x = 1; x < m; x++) g[c] += at(c, x);
+    }
+    float2 *out = flow + (size_t)blockIdx.y * npx + (size_t)y * w;
+    for (int x = 0; x < w; x++) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) g[c] += at(c, x + m) - at(c, x - m - 1);
+        const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale, h1 = g[3] * scale, h2 = g[4] * scale;
+        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+        float2 o;
+        o.x = (float)((g11 * h2 - g12 * h1) * idet);
+        o.y = (float)((g22 * h1 - g12 * h2) * idet);
+        out[x] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stage D, OPTFLOW_FARNEBACK_GAUSSIAN.  FarnebackUpdateFlow_GaussianBlur: separable Gaussian window
 // (sigma = 0.3*m, m = winsize/2), float32 throughout, replicate borders, then the same solve.
 //   column: s0 = M[y][x]*k[0];  s0 += (M[y+i][x] + M[y-i][x]) * k[i]      (i = 1..m)
@@ -622,6 +679,15 @@ void launch_blur_solve(hipStream_t s, const float *M, float *flow, int w, int h,
     dim3 grid(cdiv(w, TW), cdiv(h, B), npairs);
     hipLaunchKernelGGL(k_blur_solve, grid, dim3(256), lds, s, M, reinterpret_cast<float2 *>(flow), w, h, m, TW,
                        scale);
+}
+
+// V: npairs * 5 * w * h doubles of scratch
+void launch_blur_solve_running(hipStream_t s, const float *M, double *V, float *flow, int w, int h, int npairs, int winsize)
+{
+    const int m = winsize / 2;
+    hipLaunchKernelGGL(k_vsum_running, dim3(cdiv(w, 256), 5, npairs), dim3(256), 0, s, M, V, w, h, m);
+    hipLaunchKernelGGL(k_hsum_running_solve, dim3(cdiv(h, 64), npairs), dim3(64), 0, s, V, reinterpret_cast<float2 *>(flow), w, h, m,
+                       1. / ((double)winsize * winsize));
 }
 
 void launch_gauss_solve(hipStream_t s, const float *M, float *flow, int w, int h, int npairs, int winsize,

@@ -450,7 +450,8 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
     float *prev = nullptr;
     int pw = 0, ph = 0;
     const bool gauss = (c->prm.flags & OFARN_FLAG_FARNEBACK_GAUSSIAN) != 0;
-    const bool fused = !c->force_generic && c->prm.iterations >= 1 &&
+    const bool running = c->box_running && !gauss;      // the Gaussian window has no running sums: one order only
+    const bool fused = !c->force_generic && !running && c->prm.iterations >= 1 &&
                        (gauss ? flow_iter_gauss_supported(c->prm.winsize) : flow_iter_supported(c->prm.winsize));
     // Row pass of the level build for all levels that need one, in a single launch; tmp_of[k] is where level k's
     // rows go.  The plan is made first (offsets only), then the workspace is grown to what it needs.
@@ -462,7 +463,8 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
     HLevels &HL = wp.HL;
     const bool multi = wp.multi;
     {
-        const size_t M_need = (fused || !iterate) ? 0 : (size_t)npairs * fsz * 5;   // the fused iteration kernel keeps M on chip
+        // the fused iteration kernel keeps M on chip; the literal-order mode also needs its double column sums (10 floats per pixel)
+        const size_t M_need = (fused || !iterate) ? 0 : (size_t)npairs * fsz * (running ? 15 : 5);
         int rc = ws_reserve(c, wi, wp.tmp_need, wp.I_need, 0, M_need, 0, stream_is_capturing(s));
         if (rc) return rc;
     }
@@ -650,6 +652,9 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
             continue;
         }
         float *flow = (k == 0 && d_flow) ? d_flow : (prev == ws.flowA ? ws.flowB : ws.flowA);
+        // literal-order mode: the double column sums V sit at the (256-byte aligned) start of the M buffer, M behind them
+        double *Vk = running ? reinterpret_cast<double *>(ws.M) : nullptr;
+        float *Mk = running ? ws.M + (size_t)npairs * npx * 10 : ws.M;
         if (!prev && init_cur) {
             if (flow != init_cur)
                 HIP_TRY(hipMemcpyAsync(flow, init_cur, npx * 2 * sizeof(float) * npairs, hipMemcpyDeviceToDevice, s));
@@ -659,14 +664,15 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
                 launch_flow_upsample(s, prev, pw, ph, flow, L.w, L.h, npairs, L.d_fxofs, L.d_fxa, L.d_fyofs,
                                      L.d_fya, mul);
             });
-        timed(c, s, OFARN_STAGE_MATRICES, k, upx, [&] { launch_update_matrices(s, R_it(k), fstep, flow, ws.M, L.w, L.h, npairs); });
+        timed(c, s, OFARN_STAGE_MATRICES, k, upx, [&] { launch_update_matrices(s, R_it(k), fstep, flow, Mk, L.w, L.h, npairs); });
         for (int i = 0; i < c->prm.iterations; i++) {
             timed(c, s, OFARN_STAGE_BLUR_SOLVE, k, upx, [&] {
-                if (gauss) launch_gauss_solve(s, ws.M, flow, L.w, L.h, npairs, c->prm.winsize, c->d_gwin);
-                else launch_blur_solve(s, ws.M, flow, L.w, L.h, npairs, c->prm.winsize);
+                if (gauss) launch_gauss_solve(s, Mk, flow, L.w, L.h, npairs, c->prm.winsize, c->d_gwin);
+                else if (running) launch_blur_solve_running(s, Mk, Vk, flow, L.w, L.h, npairs, c->prm.winsize);
+                else launch_blur_solve(s, Mk, flow, L.w, L.h, npairs, c->prm.winsize);
             });
             if (i < c->prm.iterations - 1)
-                timed(c, s, OFARN_STAGE_MATRICES, k, upx, [&] { launch_update_matrices(s, R_it(k), fstep, flow, ws.M, L.w, L.h, npairs); });
+                timed(c, s, OFARN_STAGE_MATRICES, k, upx, [&] { launch_update_matrices(s, R_it(k), fstep, flow, Mk, L.w, L.h, npairs); });
         }
         prev = flow; pw = L.w; ph = L.h;
     }
@@ -834,6 +840,7 @@ int ofarn_create(const ofarn_params *params, int device, int max_w, int max_h, i
     if (const char *e = getenv("OFARN_ROW_LTR")) c->row_small_symm = e[0] == '1' ? 0 : 1;
     if (const char *e = getenv("OFARN_TILE")) c->tile_mode = e[0] != '0';
     if (const char *e = getenv("OFARN_STREAM_ZERO_COPY")) c->stream_zero_copy = e[0] != '0';
+    if (const char *e = getenv("OFARN_BOX_ORDER")) c->box_running = e[0] == '1';
     if (const char *e = getenv("OFARN_COOP_LEVELS")) c->coop_levels = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
     if (!poly_prepare(params->poly_n, params->poly_sigma, c->poly)) {
         delete c;
@@ -941,6 +948,7 @@ int ofarn_set_option(ofarn_ctx *c, const char *name, int value)
     else if (n == "push_blocks") c->push_blocks = value < 0 ? 0 : value;
     else if (n == "debug_fail_wave") c->debug_fail_wave = value;
     else if (n == "prof_dual") c->prof_dual = value != 0;
+    else if (n == "box_order") c->box_running = value != 0;
     else if (n == "coop_levels") c->coop_levels = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "debug_coop_fail") {       // test hook: as if a wait had given up (the flag the blocks poll + the one the host reads)
         if (c->coop_fail && c->coop_bar) {
@@ -965,9 +973,9 @@ int ofarn_reserve(ofarn_ctx *c, int w, int h, int n_pairs, int pairs_mode)
     const int np = n_pairs < c->max_batch ? n_pairs : c->max_batch;          // a wave never holds more
     const int nframes = pairs_mode == OFARN_PAIRS_CONSECUTIVE ? np + 1 : 2 * np;
     const bool gauss = (c->prm.flags & OFARN_FLAG_FARNEBACK_GAUSSIAN) != 0;
-    const bool fused = !c->force_generic && c->prm.iterations >= 1 &&
+    const bool fused = !c->force_generic && !(c->box_running && !gauss) && c->prm.iterations >= 1 &&
                        (gauss ? flow_iter_gauss_supported(c->prm.winsize) : flow_iter_supported(c->prm.winsize));
-    const size_t M_need = fused ? 0 : (size_t)np * w * h * 5;
+    const size_t M_need = fused ? 0 : (size_t)np * w * h * ((c->box_running && !gauss) ? 15 : 5);
     const int nws = (c->dual && n_pairs > c->max_batch) ? 2 : 1;
     for (int wi = 0; wi < nws; wi++) {
         if (wi == 1 && alloc_workspace(c, 1)) return OFARN_E_NOMEM;

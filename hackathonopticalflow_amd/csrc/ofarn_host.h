@@ -219,6 +219,8 @@ struct ofarn_ctx {
     bool prof_on = false;
     bool prof_dual = false;       // "prof_dual": per-kernel timing does NOT force the waves of a batch onto one stream (each launch is
                                   // bracketed on the stream it runs on; durations then include what co-running kernels take from it)
+    bool box_running = false;     // "box_order" = 1: the box window summed in OpenCV's literal order (k_vsum_running + k_hsum_running_solve,
+                                  // oracle OFO_BOX_RUNNING) instead of the restarted sums of the throughput kernels; unfused, 3-4 x slower
     bool force_generic = false;   // OFARN_FORCE_GENERIC=1 or ofarn_set_option: use the unfused kernels only
     int debug_fail_wave = -1;     // test hook: the (n+1)-th wave from now returns OFARN_E_NOMEM (error-path tests); -1 = off
     int tile_mode = -1;           // fused iteration: -1 = tile kernel for small grids, marching kernel otherwise; 0 / 1 = never / always

@@ -54,6 +54,8 @@ void launch_update_matrices(hipStream_t s, const float *R, int fstep, const floa
 void launch_blur_solve(hipStream_t s, const float *M, float *flow, int w, int h, int npairs,
                        int winsize);
 int blur_solve_max_winsize();
+// Stage D in OpenCV's literal running-sum order (oracle OFO_BOX_RUNNING); V: npairs * 5 * w * h doubles of scratch
+void launch_blur_solve_running(hipStream_t s, const float *M, double *V, float *flow, int w, int h, int npairs, int winsize);
 // Stage D with the Gaussian window of OPTFLOW_FARNEBACK_GAUSSIAN; d_kern: m+1 taps (host formula of optflowgf.cpp)
 void launch_gauss_solve(hipStream_t s, const float *M, float *flow, int w, int h, int npairs, int winsize,
                         const float *d_kern);

@@ -327,7 +327,13 @@ int ofarn_reserve(ofarn_ctx *ctx, int w, int h, int n_pairs, int pairs_mode);
  * build + polynomial expansion on an internal stream beside the iteration chain; 0 off, 1 the chain waits for an event behind every
  * level's expansion, 2 = default: behind the coarsest level's and then every second one's), "push_blocks" (experiment, default 0 = hipMemcpyAsync: ofarn_stream_submit pushes a flow field to page-locked host memory with a
  * kernel of that many blocks), "debug_fail_wave" (test hook: the
- * (value+1)-th wave from now fails with OFARN_E_NOMEM; -1 = off). */
+ * (value+1)-th wave from now fails with OFARN_E_NOMEM; -1 = off), "coop_levels" (see ofarn_coop_info), "prof_dual" (per-kernel timing
+ * without forcing the waves of a batch onto one stream), and
+ * "box_order" (OFARN_BOX_ORDER): 0 = default, the box window of FarnebackUpdateFlow_Blur summed with restarted running sums (the
+ * throughput kernels; oracle order OFO_BOX_BLOCKED); 1 = summed EXACTLY as optflowgf.cpp sums it -- one double running sum per
+ * column-channel down the whole image with float row differences, one double running sum along each row (oracle order
+ * OFO_BOX_RUNNING) -- bit-identical to that order, unfused, about 3-4 x slower: the mode to use when the last bits must be
+ * OpenCV's (the two orders differ by ~1e-6 px mean, 3e-5 max at 1080p).  No effect with OPTFLOW_FARNEBACK_GAUSSIAN. */
 int ofarn_set_option(ofarn_ctx *ctx, const char *name, int value);
 
 /* Device time in milliseconds of the most recent host-pointer call (hipEvent, H2D/D2H excluded). */

@@ -1515,3 +1515,49 @@ def test_error_in_the_middle_of_a_batch_leaves_the_context_usable(H, oracle, fai
         assert not eng.stream_primed(w, h)                     # a failed turn drops the session
         assert eng.stream_next(a) is None
         np.testing.assert_array_equal(eng.stream_next(b), oracle.farneback(a, b, levels=3, box_mode=oracle.BOX_BLOCKED))
+
+
+@pytest.mark.parametrize("w,h,seed,kw", [c for c in CASES if c[2] in (10, 12, 13, 14, 15, 16, 17, 19, 20, 24, 25)] +
+                         [(9, 7, 90, dict(levels=3)), (40, 1, 91, dict(levels=0, winsize=5, iterations=2)), (1, 40, 92, dict(levels=1))])
+def test_pipeline_in_opencvs_literal_summation_order(H, oracle, w, h, seed, kw):
+    """ "box_order" = 1: the box window of FarnebackUpdateFlow_Blur summed exactly as optflowgf.cpp sums it -- one double running
+    sum per column-channel down the whole image with FLOAT row differences, one double running sum along each row
+    (k_vsum_running + k_hsum_running_solve).  The result equals the oracle's OFO_BOX_RUNNING, the statement-by-statement order, BIT
+    FOR BIT -- where the throughput kernels (restarted sums) agree with it to ~1e-6 px.  Pair call, batch and streaming turn."""
+    if w > 8 and h > 8:
+        prev, nxt, _ = translated_pair(h, w, seed, max_shift=5)
+    else:
+        rng = np.random.default_rng(seed)
+        prev, nxt = rng.integers(0, 256, (h, w)).astype(np.uint8), rng.integers(0, 256, (h, w)).astype(np.uint8)
+    ref = oracle.farneback(prev, nxt, box_mode=oracle.BOX_RUNNING, **kw)
+    with H.FarnebackEngine(w, h, 2, **kw) as eng:
+        eng.set_option("box_order", 1)
+        np.testing.assert_array_equal(eng.calc(prev, nxt), ref)
+        flow, _, _ = eng.calc_batch(np.stack([prev, nxt, nxt, prev]), want_danger=False)
+        np.testing.assert_array_equal(flow[0], ref)
+        np.testing.assert_array_equal(flow[1], oracle.farneback(nxt, prev, box_mode=oracle.BOX_RUNNING, **kw))
+        assert eng.stream_next(prev) is None
+        np.testing.assert_array_equal(eng.stream_next(nxt), ref)
+        np.testing.assert_array_equal(eng.calc_reuse(nxt, prev), oracle.farneback(nxt, prev, box_mode=oracle.BOX_RUNNING, **kw))
+        eng.set_option("box_order", 0)                      # and back to the throughput order on the same context
+        np.testing.assert_array_equal(eng.calc(prev, nxt), oracle.farneback(prev, nxt, box_mode=oracle.BOX_BLOCKED, **kw))
+
+
+def test_literal_order_1080p_config2_and_flags(H, oracle):
+    """The literal order at BASELINE config 2's size (1920x1080, levels 5), on the warped family, with OPTFLOW_USE_INITIAL_FLOW, and
+    with OPTFLOW_FARNEBACK_GAUSSIAN (whose window has one order only: the option changes nothing there)."""
+    prev, nxt, _ = translated_pair(1080, 1920, 2001)
+    with H.FarnebackEngine(1920, 1080, 1, levels=5) as eng:
+        eng.set_option("box_order", 1)
+        got = eng.calc(prev, nxt)
+        np.testing.assert_array_equal(got, oracle.farneback(prev, nxt, levels=5, box_mode=oracle.BOX_RUNNING))
+        fast = H.calculate_optical_flow(prev, nxt, levels=5)
+        e = epe(got, fast)
+        assert 0 < e.max() <= TOL_MAX_EPE and e.mean() <= TOL_MEAN_EPE          # the two orders differ, a little
+    a, b, _, _ = warped_pair(251, 333, 5, zoom=1.04, angle_deg=2.0)
+    init = (np.random.default_rng(3).standard_normal((251, 333, 2)) * 2).astype(np.float32)
+    for kw, init_flow in ((dict(levels=3), None), (dict(levels=2, flags=4), init), (dict(levels=2, flags=256), None), (dict(levels=2, winsize=10), None)):
+        with H.FarnebackEngine(333, 251, 1, **kw) as eng:
+            eng.set_option("box_order", 1)
+            got = eng.calc(a, b, init_flow.copy() if init_flow is not None else None)
+            np.testing.assert_array_equal(got, oracle.farneback(a, b, box_mode=oracle.BOX_RUNNING, init_flow=init_flow, **kw))
