@@ -658,9 +658,6 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the CPU baseline (the GPU box's CPU share per GPU is 16)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel hipEvent timing")
     ap.add_argument("--prof-table", action="store_true", help="print per-(stage, level) timing rows to stderr")
-    ap.add_argument("--dual-timed", action="store_true",
-                    help="experiment: the TIMED region runs the batch as two waves on the library's two internal streams with per-kernel "
-                         "timing on (each launch bracketed on its own stream)")
     ap.add_argument("--no-two-stream", action="store_true",
                     help="skip the informational second measurement with per-kernel timing off (two internal streams)")
     ap.add_argument("--no-family-check", action="store_true",
@@ -737,11 +734,7 @@ def main():
         if B < 1:
             raise SystemExit(f"{global_pairs} pairs cannot be sharded over {world} ranks")
     wave = min(args.wave, B)
-    if args.dual_timed:
-        wave = (min(args.wave, B) + 1) // 2
     eng = ofa.FarnebackEngine(W, H, wave, dev_index, **params)
-    if args.dual_timed:
-        eng.set_option("prof_dual", 1)
     P = len(ofa.grid_points(W, H, 30))
     plan = ofa.level_plan(W, H, **params)
 

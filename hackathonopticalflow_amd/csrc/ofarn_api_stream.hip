@@ -343,6 +343,17 @@ int ofarn_calc_reuse(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next,
             if (memcmp(kept + (size_t)y * w, h_prev + (size_t)y * stride_prev, (size_t)w) != 0) return false;
         return true;
     };
+    // A cheap look before the optimistic launch (a hint only -- the full comparison below decides): 17 rows spread over the frame.
+    // A caller who passes unrelated pairs differs here already and goes straight to the both-frames path instead of paying for a
+    // turn that is thrown away (1.7 instead of 1.0 ms per call).
+    auto sample_same = [&]() -> bool {
+        const uint8_t *kept = st.h_keep[kn ^ 1];
+        for (int k = 0; k <= 16; k++) {
+            const int y = (int)((long long)(h - 1) * k / 16);
+            if (memcmp(kept + (size_t)y * w, h_prev + (size_t)y * stride_prev, (size_t)w) != 0) return false;
+        }
+        return true;
+    };
     auto give_up = [&](int code) { st.have = false; st.keep_valid = false; (void)end_call(c, s); return code; };
     float *d_out = c->st_flow;
     bool direct = false;
@@ -371,6 +382,7 @@ int ofarn_calc_reuse(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next,
     if (!next_dense) keep_next();
     bool reuse = false;
     if (cand && use_init) cand = reuse = same_as_kept();    // in/out flow: nothing may be overwritten before we know
+    else if (cand && !sample_same()) cand = false;
     if (cand) {
         if ((rc = enqueue_pair()) < 0) return give_up(rc);
         keep_next();                                        // both beside the device's work
