@@ -90,6 +90,13 @@ struct ofarn_multi {
     };
     std::vector<Buf> buf;
     unsigned long long gathers = 0;     // ncclAllGather calls issued so far (two per device and batch)
+    // OFARN_MULTI_LOOPBACK=1 (tests): the listed devices may repeat -- several ranks on ONE GPU, each with its own context, worker and
+    // stream -- and the all-gather is replaced by the copies it stands for (every rank fetches every rank's block with
+    // hipMemcpyAsync behind an event of the producing rank).  RCCL cannot put two ranks on one device, and the GPU box has one GPU:
+    // this is how the G > 1 branches (shards, in-place offsets, the `even` shortcut, compaction, host copies, the worker threads)
+    // run on hardware at all.  Never set in production.
+    bool loopback = false;
+    std::vector<hipEvent_t> ev_maps;    // loopback: rank r's danger maps are written
     double last_ms = 0;
 };
 
@@ -210,8 +217,22 @@ template <typename F> int on_all_devices(ofarn_multi *m, F &&fn) { return on_dev
 // in place (send buffer = recv buffer + rank * cap * P), all devices inside one group.
 int gather_maps(ofarn_multi *m, const GatherPlan &gp, const std::vector<uint8_t *> &gmask, const std::vector<uint8_t *> &gv)
 {
-    Rccl &R = rccl();
     const size_t cnt = gp.rank_bytes();
+    if (m->loopback) {
+        // what the all-gather does, spelled out: after rank r's maps are complete (its event), every rank g copies rank r's block
+        // into its own padded array at the same offset
+        for (int r = 0; r < m->n; r++) HIP_TRY(hipEventRecord(m->ev_maps[r], m->stream[r]));
+        for (int g = 0; g < m->n; g++)
+            for (int r = 0; r < m->n; r++) {
+                if (r == g) continue;
+                HIP_TRY(hipStreamWaitEvent(m->stream[g], m->ev_maps[r], 0));
+                HIP_TRY(hipMemcpyAsync(gmask[g] + gp.gather_off[r], gmask[r] + gp.gather_off[r], cnt, hipMemcpyDeviceToDevice, m->stream[g]));
+                HIP_TRY(hipMemcpyAsync(gv[g] + gp.gather_off[r], gv[r] + gp.gather_off[r], cnt, hipMemcpyDeviceToDevice, m->stream[g]));
+            }
+        m->gathers += 2ull * m->n;
+        return OFARN_OK;
+    }
+    Rccl &R = rccl();
     ncclResult_t r = R.GroupStart();
     for (int g = 0; g < m->n && r == ncclSuccess; g++) {
         r = R.AllGather(gmask[g] + gp.gather_off[g], gmask[g], cnt, ncclUint8, m->comm[g], m->stream[g]);
@@ -390,19 +411,24 @@ int ofarn_multi_create(const ofarn_params *params, const int *devices, int n_dev
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(OFARN_E_HIP, "no HIP device visible; libofarn has no CPU path");
+    const char *lb = getenv("OFARN_MULTI_LOOPBACK");
+    const bool loopback = lb && lb[0] == '1';
     std::vector<int> dev(n_devices);
     for (int g = 0; g < n_devices; g++) {
-        dev[g] = devices ? devices[g] : g;
+        dev[g] = devices ? devices[g] : (loopback ? g % ndev : g);
         if (dev[g] < 0 || dev[g] >= ndev) return fail(OFARN_E_INVALID, "device %d out of range [0, %d)", dev[g], ndev);
-        for (int q = 0; q < g; q++) if (dev[q] == dev[g]) return fail(OFARN_E_INVALID, "device %d listed twice (one rank per GPU)", dev[g]);
+        for (int q = 0; q < g && !loopback; q++)
+            if (dev[q] == dev[g]) return fail(OFARN_E_INVALID, "device %d listed twice (one rank per GPU)", dev[g]);
     }
     Rccl &R = rccl();
-    if (!R.error.empty()) return fail(OFARN_E_HIP, "%s", R.error.c_str());
+    if (!loopback && !R.error.empty()) return fail(OFARN_E_HIP, "%s", R.error.c_str());
     ofarn_multi *m = new ofarn_multi();
     m->n = n_devices;
     m->dev = dev;
     m->prm = *params;
     m->max_w = max_w; m->max_h = max_h; m->max_batch = max_batch_per_device;
+    m->loopback = loopback;
+    m->ev_maps.assign(n_devices, nullptr);
     m->ctx.assign(n_devices, nullptr);
     m->stream.assign(n_devices, nullptr);
     m->buf.resize(n_devices);
@@ -415,9 +441,11 @@ int ofarn_multi_create(const ofarn_params *params, const int *devices, int n_dev
         int r = ofarn_create(params, dev[g], max_w, max_h, max_batch_per_device, &m->ctx[g]);
         if (!r && hipStreamCreateWithFlags(&m->stream[g], hipStreamNonBlocking) != hipSuccess)
             r = fail(OFARN_E_HIP, "stream creation on device %d failed", dev[g]);
+        if (!r && loopback && hipEventCreateWithFlags(&m->ev_maps[g], hipEventDisableTiming) != hipSuccess)
+            r = fail(OFARN_E_HIP, "event creation on device %d failed", dev[g]);
         return r;
     });
-    if (!rc)
+    if (!rc && !loopback)
         rc = on_devices(m, 0, 1, [&](int) -> int {
             m->comm.assign(n_devices, nullptr);
             const ncclResult_t r = R.CommInitAll(m->comm.data(), n_devices, dev.data());
@@ -444,6 +472,7 @@ void ofarn_multi_destroy(ofarn_multi *m)
             ofarn_multi::Buf &b = m->buf[g];
             for (void *p : {(void *)b.frames, (void *)b.flow, (void *)b.gmask, (void *)b.gv, (void *)b.mask_all, (void *)b.v_all}) if (p) (void)hipFree(p);
             if (m->stream[g]) (void)hipStreamDestroy(m->stream[g]);
+            if (g < (int)m->ev_maps.size() && m->ev_maps[g]) (void)hipEventDestroy(m->ev_maps[g]);
             if (m->ctx[g]) ofarn_destroy(m->ctx[g]);
             return OFARN_OK;
         });

@@ -1003,17 +1003,15 @@ def _params_dict(p: OfarnParams):
 # Several GPUs in one process (C-ABI ofarn_multi_*; the torch.distributed form of the same sharding is distributed.py)
 # ---------------------------------------------------------------------------------------------
 def _share_rccl_with_torch():
-    """One RCCL per process: PyTorch bundles its own librccl.so; load that copy first (if torch is installed) so that the
-    dlopen inside ofarn_multi_create finds it by soname instead of bringing in the system copy next to it."""
+    """One RCCL per process: PyTorch bundles its own librccl.so.  If torch is installed it is IMPORTED here, before ofarn_multi_create
+    dlopens librccl: torch then loads its RCCL (and the libraries that copy depends on) in its own order, and the dlopen finds that
+    copy by soname.  Loading torch's librccl.so on its own first and importing torch LATER in the same process ended in a double free
+    at interpreter exit (round 4: `pytest -k create_errors` alone); in the other order, and without torch, nothing of the kind."""
     try:
         import importlib.util
-        spec = importlib.util.find_spec("torch")
-        if spec is None or not spec.submodule_search_locations:
-            return
-        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
-        if os.path.exists(cand):
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-    except OSError:
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
+    except Exception:   # noqa: BLE001 -- a broken torch installation must not keep the C-ABI path from working
         pass
 
 

@@ -193,3 +193,51 @@ def test_multi_leaves_the_callers_device_and_thread_alone(H, oracle):
     np.testing.assert_array_equal(flow, f1)
     np.testing.assert_array_equal(mask, m1)
     np.testing.assert_array_equal(v, v1)
+
+
+@pytest.mark.parametrize("G", [2, 3, 4, 8])
+def test_multi_rank_branches_run_on_one_gpu_in_loopback(H, oracle, monkeypatch, G):
+    """the G > 1 branches of ofarn_multi_* -- one worker thread per rank, ragged and empty shards, the in-place gather at
+    rank * cap * P, the `even` shortcut straight into caller arrays, the compaction of ragged shards, rank 0's host copy -- had never
+    run on hardware: RCCL cannot put two ranks on one GPU, and the box has one.  OFARN_MULTI_LOOPBACK=1 lists the same device G
+    times (one context, worker and stream per rank) and replaces the all-gather by the copies it stands for (every rank fetches every
+    rank's block behind an event of the producer); everything else is the production path.  Results must equal the single context's
+    for even, ragged and fewer-pairs-than-ranks batches, both pair modes, host and device-resident variants."""
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("OFARN_MULTI_LOOPBACK", "1")
+    w, h, kw = 200, 150, dict(levels=2)
+    P = len(H.grid_points(w, h, 30))
+    with H.MultiGpuEngine([0] * G, w, h, 3, **kw) as multi, H.FarnebackEngine(w, h, 8, **kw) as one:
+        assert multi.info()["devices"] == [0] * G
+        for n_pairs, mode in ((2 * G, 0), (2 * G + 1, 0), (G - 1, 0), (G + 2, 1), (1, 1)):
+            n_frames = n_pairs + 1 if mode == 1 else 2 * n_pairs
+            frames, _ = warped_pairs(n_frames // 2 + 1, h, w, 5300 + n_pairs)
+            frames = frames[:n_frames]
+            f1, m1, v1 = one.calc_batch(frames, mode)
+            flow, mask, v = multi.calc_batch(frames, mode)                       # host variant: rank 0's gathered maps come back
+            np.testing.assert_array_equal(flow, f1)
+            np.testing.assert_array_equal(mask, m1)
+            np.testing.assert_array_equal(v, v1)
+            if mode == 1:
+                continue
+            # device-resident variant: every rank's gathered arrays must hold ALL pairs' maps in global order
+            d_frames, d_flow, d_m, d_v = [], [], [], []
+            for g in range(G):
+                s, c = H.shard_pairs_c(n_pairs, g, G)
+                d_frames.append(torch.from_numpy(frames[2 * s:2 * (s + c)].copy()).cuda() if c else torch.empty(0, dtype=torch.uint8, device="cuda"))
+                d_flow.append(torch.empty((c, h, w, 2), dtype=torch.float32, device="cuda"))
+                d_m.append(torch.full((n_pairs, P), 0xEE, dtype=torch.uint8, device="cuda"))
+                d_v.append(torch.full((n_pairs, P), 0xEE, dtype=torch.uint8, device="cuda"))
+            torch.cuda.synchronize()
+            multi.calc_batch_device(d_frames, n_pairs, w, h, H.PAIRS_INDEPENDENT, d_flow, d_m, d_v)
+            multi.synchronize()
+            for g in range(G):
+                s, c = H.shard_pairs_c(n_pairs, g, G)
+                np.testing.assert_array_equal(d_flow[g].cpu().numpy(), f1[s:s + c])
+                np.testing.assert_array_equal(d_m[g].cpu().numpy(), m1)
+                np.testing.assert_array_equal(d_v[g].cpu().numpy(), v1)
+    # the first pair of the last batch against the oracle, so that "equal to the single context" means "right"
+    np.testing.assert_array_equal(f1[0], oracle.farneback(frames[0], frames[1], box_mode=oracle.BOX_BLOCKED, **kw))
+    monkeypatch.delenv("OFARN_MULTI_LOOPBACK")
+    with pytest.raises(ValueError):
+        H.MultiGpuEngine([0, 0], 64, 48, 2)                   # without the test switch: one rank per GPU
