@@ -1243,8 +1243,13 @@ int ofarn_calc(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next, int w
     const size_t fsz = (size_t)w * h;
     if ((rc = ensure_staging(c, 2 * fsz, fsz * 2 * sizeof(float), 0))) return rc;
     if ((rc = begin_call(c, c->stream))) return rc;
-    HIP_TRY(hipMemcpy2DAsync(c->st_frames, w, h_prev, stride, w, h, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpy2DAsync(c->st_frames + fsz, w, h_next, stride, w, h, hipMemcpyHostToDevice, c->stream));
+    if (stride == w) {      // dense rows: plain copies (a 2-D copy of pageable memory is staged row by row)
+        HIP_TRY(hipMemcpyAsync(c->st_frames, h_prev, fsz, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->st_frames + fsz, h_next, fsz, hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIP_TRY(hipMemcpy2DAsync(c->st_frames, w, h_prev, stride, w, h, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpy2DAsync(c->st_frames + fsz, w, h_next, stride, w, h, hipMemcpyHostToDevice, c->stream));
+    }
     const bool use_init = (c->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW) != 0;
     if (use_init)   // cv2: `flow` is an in/out argument holding the initial flow
         HIP_TRY(hipMemcpyAsync(c->st_flow, h_flow, fsz * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
