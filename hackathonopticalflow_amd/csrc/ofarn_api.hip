@@ -429,21 +429,24 @@ static int coop_level_range(ofarn_ctx *c, int npairs, bool streaming, int *block
 }
 
 int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, int pairs_mode, int w,
-             int h, float *d_flow, uint8_t *d_mask, uint8_t *d_v, int wi, const float *d_init, ofarn_ctx::Stream *st, bool skip_ab)
+             int h, float *d_flow, uint8_t *d_mask, uint8_t *d_v, int wi, const float *d_init, ofarn_ctx::Stream *st, bool skip_ab,
+             bool st_pair)
 {
     ofarn_ctx::Workspace &ws = c->ws[wi];
     // streaming turn: one new frame into slot `snew`; the pair is (slot cur, slot snew), one pair
-    const int snew = st ? (st->have ? st->cur ^ 1 : 0) : 0;
-    const bool iterate = !st || st->have;
+    // st_pair (the session holds nothing): d_frames are BOTH frames of a pair; they go to slots 0 and 1 in one set of launches and
+    // are iterated at once -- the session afterwards holds the second frame in slot 1
+    const int snew = st ? ((st->have && !st_pair) ? st->cur ^ 1 : 0) : 0;
+    const bool iterate = !st || st->have || st_pair;
     if (st) npairs = 1;
-    const int fstep = st ? (snew > st->cur ? 1 : -1) : (pairs_mode == OFARN_PAIRS_CONSECUTIVE ? 1 : 2);
-    const int nframes = st ? 1 : (pairs_mode == OFARN_PAIRS_CONSECUTIVE ? npairs + 1 : 2 * npairs);
+    const int fstep = st ? (st_pair ? 1 : (snew > st->cur ? 1 : -1)) : (pairs_mode == OFARN_PAIRS_CONSECUTIVE ? 1 : 2);
+    const int nframes = st ? (st_pair ? 2 : 1) : (pairs_mode == OFARN_PAIRS_CONSECUTIVE ? npairs + 1 : 2 * npairs);
     // where level k's polynomial expansions are written (stages A + B) and read (iterations)
     auto R_ab = [&](int k) -> float * {
         return st ? st->R + st->off[k] + (size_t)snew * r_frame_stride((size_t)c->lv[k].w * c->lv[k].h) : ws.R;
     };
     auto R_it = [&](int k) -> const float * {
-        return st ? st->R + st->off[k] + (size_t)st->cur * r_frame_stride((size_t)c->lv[k].w * c->lv[k].h) : ws.R;
+        return st ? st->R + st->off[k] + (size_t)(st_pair ? 0 : st->cur) * r_frame_stride((size_t)c->lv[k].w * c->lv[k].h) : ws.R;
     };
     const size_t fsz = (size_t)w * h;
     const int nlev = (int)c->lv.size() - 1;

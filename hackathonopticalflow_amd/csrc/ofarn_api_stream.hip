@@ -103,19 +103,21 @@ int grow_u8(ofarn_ctx *c, uint8_t **p, size_t *cap, size_t need, const char *wha
 
 // One turn on stream s with the new gray frame already on the device.  Returns OFARN_OK (flow written) or
 // OFARN_STREAM_PRIMED (first frame of a session: nothing to pair it with).
-int stream_turn(ofarn_ctx *c, hipStream_t s, const uint8_t *d_gray, int w, int h, float *d_flow, uint8_t *d_mask, uint8_t *d_v)
+int stream_turn(ofarn_ctx *c, hipStream_t s, const uint8_t *d_gray, int w, int h, float *d_flow, uint8_t *d_mask, uint8_t *d_v,
+                bool pair = false)
 {
     ofarn_ctx::Stream &st = c->stream_state;
-    const bool had = st.have;
+    if (pair) st.have = false;                   // pair turn: d_gray holds both frames, the session starts over with them
+    const bool had = st.have || pair;
     const bool use_init = (c->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW) != 0;
     int rc = run_wave(c, s, d_gray, 1, OFARN_PAIRS_CONSECUTIVE, w, h, d_flow, had ? d_mask : nullptr, had ? d_v : nullptr, 0,
-                      (use_init && had) ? d_flow : nullptr, &st);
+                      (use_init && had) ? d_flow : nullptr, &st, false, pair);
     if (rc) {
         st.have = false;                         // a half-written slot must not be paired with anything
         if (c->aux[0]) (void)hipStreamSynchronize(c->aux[0]);   // stages A + B may have been left running beside the caller's stream
         return rc;
     }
-    st.cur = had ? st.cur ^ 1 : 0;
+    st.cur = pair ? 1 : (had ? st.cur ^ 1 : 0);
     st.have = true;
     st.turns++;
     st.view_flow_valid = had && d_flow == c->st_flow && d_flow != nullptr;
@@ -311,7 +313,7 @@ int ofarn_calc_reuse(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next,
     if (stride_prev < w || stride_next < w) return fail(OFARN_E_INVALID, "stride %d / %d < width %d", stride_prev, stride_next, w);
     ofarn_ctx::Stream &st = c->stream_state;
     const size_t fsz = (size_t)w * h, flow_bytes = fsz * 2 * sizeof(float);
-    if ((rc = grow_u8(c, &st.d_frame, &st.frame_cap, fsz, "streaming frame buffer"))) return rc;
+    if ((rc = grow_u8(c, &st.d_frame, &st.frame_cap, 2 * fsz, "streaming frame buffer"))) return rc;     // room for a pair (miss path)
     if ((rc = ensure_staging(c, 0, flow_bytes, 0))) return rc;
     hipStream_t s = c->stream;
     if (fsz > st.keep_cap) {
@@ -365,13 +367,15 @@ int ofarn_calc_reuse(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next,
     const bool next_dense = stride_next == w;
     bool next_kept = false;
     auto keep_next = [&]() { if (!next_kept) { stage(st.h_keep[kn], h_next, stride_next); next_kept = true; } };
-    // one turn of the session with `next`; everything enqueued, nothing waited for
-    auto enqueue_pair = [&]() -> int {
-        HIP_TRY(hipMemcpyAsync(st.d_frame, next_kept ? st.h_keep[kn] : h_next, fsz, hipMemcpyHostToDevice, s));
+    // one turn of the session with `next` -- or, with both = true, a pair turn from (prev, next): the session starts over and both
+    // frames go through the level builds and expansions in ONE set of launches; everything enqueued, nothing waited for
+    auto enqueue_pair = [&](bool both) -> int {
+        if (both) HIP_TRY(hipMemcpyAsync(st.d_frame, st.h_keep[kn ^ 1], fsz, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(st.d_frame + (both ? fsz : 0), next_kept ? st.h_keep[kn] : h_next, fsz, hipMemcpyHostToDevice, s));
         if (use_init) HIP_TRY(hipMemcpyAsync(c->st_flow, h_flow, flow_bytes, hipMemcpyHostToDevice, s));
         HIP_TRY(hipEventRecord(c->ev0, s));
         c->coop_now = !use_init;
-        const int turn = stream_turn(c, s, st.d_frame, w, h, d_out, nullptr, nullptr);
+        const int turn = stream_turn(c, s, st.d_frame, w, h, d_out, nullptr, nullptr, both);
         c->coop_now = false;
         if (turn < 0) return turn;
         if (turn != OFARN_OK) return fail(OFARN_E_HIP, "internal: the session held no frame to pair with");
@@ -384,7 +388,7 @@ int ofarn_calc_reuse(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next,
     if (cand && use_init) cand = reuse = same_as_kept();    // in/out flow: nothing may be overwritten before we know
     else if (cand && !sample_same()) cand = false;
     if (cand) {
-        if ((rc = enqueue_pair()) < 0) return give_up(rc);
+        if ((rc = enqueue_pair(false)) < 0) return give_up(rc);
         keep_next();                                        // both beside the device's work
         if (!use_init) reuse = same_as_kept();
     }
@@ -393,11 +397,7 @@ int ofarn_calc_reuse(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next,
         // be running is ordered in front of this on the stream and its output is overwritten.
         st.have = false;
         stage(st.h_keep[kn ^ 1], h_prev, stride_prev);
-        if (hipMemcpyAsync(st.d_frame, st.h_keep[kn ^ 1], fsz, hipMemcpyHostToDevice, s) != hipSuccess)
-            return give_up(fail(OFARN_E_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(hipGetLastError())));
-        const int turn = stream_turn(c, s, st.d_frame, w, h, nullptr, nullptr, nullptr);
-        if (turn < 0) return give_up(turn);
-        if ((rc = enqueue_pair()) < 0) return give_up(rc);
+        if ((rc = enqueue_pair(true)) < 0) return give_up(rc);
         keep_next();
         st.reuse_misses++;
     } else st.reuse_hits++;

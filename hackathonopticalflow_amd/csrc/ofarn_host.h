@@ -274,7 +274,7 @@ int end_call(ofarn_ctx *c, hipStream_t s);
 // polynomial expansions go to the free slot of st->R, and -- if a previous frame is held -- the pair (previous, new) is iterated.
 int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, int pairs_mode, int w, int h, float *d_flow,
              uint8_t *d_mask, uint8_t *d_v, int wi = 0, const float *d_init = nullptr, ofarn_ctx::Stream *st = nullptr,
-             bool skip_ab = false);
+             bool skip_ab = false, bool st_pair = false);
 // Behind a host-synchronous entry point's synchronisation: did a cooperative launch give up a wait?  If so the context stops using
 // cooperative launches, the barrier state is reset and true is returned (the caller reruns the iterations).
 bool coop_gave_up(ofarn_ctx *c);
