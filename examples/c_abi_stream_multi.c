@@ -77,6 +77,32 @@ int main(int argc, char **argv)
     }
     printf("%s: frame loop, %d turns of %dx%d, levels=%d: %.3f ms of device time per turn\n", ofarn_version(), n - 1, w, h, prm.levels,
            ms / (n - 1));
+    /* 1b. the same loop with the PAIR signature of the reference's call (DenseOF.py:519-525: flow = calculate_optical_flow(prev_gray,
+     * gray); prev_gray = gray): ofarn_calc_reuse is stateless in effect -- it reuses the frame on the device only when every byte of
+     * `prev` equals the frame it was last given as `next`.  Here: the loop (reused from the second call on), then the held frame
+     * edited in place by one byte (noticed: not reused, and the flow is that of the edited frame = ofarn_calc's). */
+    {
+        int reused = 0, hits = 0;
+        for (int i = 1; i < n; i++) {
+            if ((rc = ofarn_calc_reuse(ctx, frames + (size_t)(i - 1) * npx, frames + (size_t)i * npx, w, h, w, w, (float *)pinned, &reused)))
+                return die("ofarn_calc_reuse", rc);
+            hits += reused;
+            if (memcmp(all_stream + (size_t)(i - 1) * npx * 2, pinned, fbytes) != 0) { fprintf(stderr, "ofarn_calc_reuse differs from the loop at pair %d\n", i - 1); return 1; }
+        }
+        if (hits != n - 2) { fprintf(stderr, "expected %d reuses, got %d\n", n - 2, hits); return 1; }
+        uint8_t *edited = (uint8_t *)malloc(npx);
+        float *ref = (float *)malloc(fbytes);
+        if (!edited || !ref) return 2;
+        memcpy(edited, frames + (size_t)(n - 1) * npx, npx);        /* the frame the device holds now ... */
+        edited[npx / 2 + 3] ^= 0x40;                                  /* ... with one byte changed */
+        if ((rc = ofarn_calc_reuse(ctx, edited, frames, w, h, w, w, (float *)pinned, &reused))) return die("ofarn_calc_reuse", rc);
+        if ((rc = ofarn_calc(ctx, edited, frames, w, h, w, ref))) return die("ofarn_calc", rc);
+        if (reused || memcmp(ref, pinned, fbytes) != 0) { fprintf(stderr, "an edited frame was reused or gave another flow than ofarn_calc\n"); return 1; }
+        unsigned long long h_ = 0, m_ = 0;
+        ofarn_calc_reuse_info(ctx, &h_, &m_);
+        printf("pair signature with exact reuse: %llu reused, %llu started over (one of them after a one-byte edit)\n", h_, m_);
+        free(edited); free(ref);
+    }
     ofarn_host_free(pinned);
     ofarn_destroy(ctx);
 
