@@ -309,50 +309,94 @@ __global__ __launch_bounds__(256) void k_blur_solve(const float *__restrict__ M,
 //   k_hsum_running_solve: a thread per row marches along ALL columns:           g += V[x+m] - V[x-m-1], solve, store
 // 80 B per pixel of extra HBM traffic and two sequential chains: a verification mode (3-4 x slower), not the default.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_vsum_running(const float *__restrict__ M, double *__restrict__ V, int w, int h, int m)
+// Both chains run through LDS tiles so that every global access is a whole-wave contiguous segment although one kernel walks
+// down columns and the other along rows: k_vsum_running leaves its sums TRANSPOSED (VT[c][x][y]: 64 steps of 64 columns are
+// collected in a tile and written as 64 runs of 64 consecutive y), k_hsum_running_solve reads them with its lanes on consecutive
+// rows (contiguous again) and transposes its 64 x 64 results back before storing flow rows.  The first form of these kernels
+// (plain V[c][y][x], a lane per row striding w * 8 bytes) ran at 5 Gpx/s; see profiles/r04_literal_order.txt.
+constexpr int RS_T = 64;                  // threads per block (one wave): columns of k_vsum_running, rows of k_hsum_running_solve
+constexpr int RS_S = 32;                  // chain steps collected in LDS before they are written out transposed (16.6 KB per block)
+
+__global__ __launch_bounds__(RS_T) void k_vsum_running(const float *__restrict__ M, double *__restrict__ VT, int w, int h, int m)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= w) return;
+    extern __shared__ unsigned char rs_smem[];
+    double (*tile)[RS_T + 1] = reinterpret_cast<double (*)[RS_T + 1]>(rs_smem);                       // [step][column]
+    float *ring = reinterpret_cast<float *>(rs_smem + sizeof(double) * RS_S * (RS_T + 1));            // [2m+2][RS_T]: M rows still in the window
+    const int RING = 2 * m + 2;
+    const int lane = threadIdx.x, x0 = blockIdx.x * RS_T;
+    const int xc = min(x0 + lane, w - 1);                       // lanes beyond the frame redo the last column and store nothing
     const size_t npx = (size_t)w * h;
     const size_t plane = ((size_t)blockIdx.z * 5 + blockIdx.y) * npx;
-    const float *src = M + plane + x;
-    double *dst = V + plane + x;
-    auto row = [&](int y) { return src[(size_t)y * w]; };
-    double vsum = (double)(row(0) * (float)(m + 2));                   // vsum[x] = srow0[x] * (m + 2): a float product
-    for (int y = 1; y < m; y++) vsum += (double)row(y < h - 1 ? y : h - 1);
-    for (int y = 0; y < h; y++) {
-        const float s0 = row(y - m - 1 > 0 ? y - m - 1 : 0), s1 = row(y + m < h - 1 ? y + m : h - 1);
-        vsum += (double)(s1 - s0);                                      // the row difference is rounded to float first
-        dst[(size_t)y * w] = vsum;
+    const float *src = M + plane + xc;
+    double *dst = VT + plane;
+    auto fetch = [&](int r) { const float v = src[(size_t)r * w]; ring[(r % RING) * RS_T + lane] = v; return v; };
+    auto held = [&](int r) { return ring[(r % RING) * RS_T + lane]; };          // a lane only ever reads what it wrote itself
+    double vsum = (double)(fetch(0) * (float)(m + 2));                          // vsum[x] = srow0[x] * (m + 2): a float product
+    for (int y = 1; y < m; y++) vsum += (double)(y <= h - 1 ? fetch(y) : held(h - 1));
+    const int half = lane >> 5, l32 = lane & 31;
+    for (int y0 = 0; y0 < h; y0 += RS_S) {
+        const int ny = min(RS_S, h - y0);
+        for (int t = 0; t < ny; t++) {
+            const int y = y0 + t;
+            const float s1 = (y + m <= h - 1) ? fetch(y + m) : held(h - 1);     // rows 0 .. m-1 were fetched above, row y+m >= m is new
+            const float s0 = held(y - m - 1 > 0 ? y - m - 1 : 0);
+            vsum += (double)(s1 - s0);                                          // the row difference is rounded to float first
+            tile[t][lane] = vsum;
+        }
+        __syncthreads();
+        // two columns per store instruction: each half-wave writes RS_S consecutive y of one column (256 B)
+        for (int j = 0; j < RS_T; j += 2)
+            if (x0 + j + half < w && l32 < ny) dst[(size_t)(x0 + j + half) * h + y0 + l32] = tile[l32][j + half];
+        __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(64) void k_hsum_running_solve(const double *__restrict__ V, float2 *__restrict__ flow, int w, int h, int m,
-                                                          double scale)
+__global__ __launch_bounds__(RS_T) void k_hsum_running_solve(const double *__restrict__ VT, float2 *__restrict__ flow, int w, int h, int m,
+                                                            double scale)
 {
-    const int y = blockIdx.x * 64 + threadIdx.x;
-    if (y >= h) return;
+    __shared__ float2 tile[RS_S][RS_T + 1];                                     // [column step][row]
+    const int lane = threadIdx.x, y0 = blockIdx.x * RS_T;
+    const int yc = min(y0 + lane, h - 1);
     const size_t npx = (size_t)w * h;
     const double *v[5];
 #pragma unroll
-    for (int c = 0; c < 5; c++) v[c] = V + ((size_t)blockIdx.y * 5 + c) * npx + (size_t)y * w;
-    auto at = [&](int c, int x) { return v[c][x < 0 ? 0 : (x > w - 1 ? w - 1 : x)]; };     // the replicated borders of vsum[]
+    for (int c = 0; c < 5; c++) v[c] = VT + ((size_t)blockIdx.y * 5 + c) * npx + yc;
+    auto at = [&](int c, int x) { return v[c][(size_t)(x < 0 ? 0 : (x > w - 1 ? w - 1 : x)) * h]; };   // the replicated borders of vsum[]
     double g[5];
 #pragma unroll
     for (int c = 0; c < 5; c++) {
         g[c] = at(c, 0) * (m + 2);
         for (int x = 1; x < m; x++) g[c] += at(c, x);
     }
-    float2 *out = flow + (size_t)blockIdx.y * npx + (size_t)y * w;
-    for (int x = 0; x < w; x++) {
+    float2 *out = flow + (size_t)blockIdx.y * npx;
+    const int ny = min(RS_T, h - y0);
+    const int half = lane >> 5, l32 = lane & 31;
+    double in[5], lv[5];
 #pragma unroll
-        for (int c = 0; c < 5; c++) g[c] += at(c, x + m) - at(c, x - m - 1);
-        const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale, h1 = g[3] * scale, h2 = g[4] * scale;
-        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-        float2 o;
-        o.x = (float)((g11 * h2 - g12 * h1) * idet);
-        o.y = (float)((g22 * h1 - g12 * h2) * idet);
-        out[x] = o;
+    for (int c = 0; c < 5; c++) { in[c] = at(c, m); lv[c] = at(c, -m - 1); }
+    for (int x0 = 0; x0 < w; x0 += RS_S) {
+        const int nx = min(RS_S, w - x0);
+        for (int j = 0; j < nx; j++) {
+            const int x = x0 + j;
+            double in1[5], lv1[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) { in1[c] = at(c, x + 1 + m); lv1[c] = at(c, x - m); }           // the next step's values, ahead of this step's chain
+#pragma unroll
+            for (int c = 0; c < 5; c++) g[c] += in[c] - lv[c];
+            const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale, h1 = g[3] * scale, h2 = g[4] * scale;
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            float2 o;
+            o.x = (float)((g11 * h2 - g12 * h1) * idet);
+            o.y = (float)((g22 * h1 - g12 * h2) * idet);
+            tile[j][lane] = o;
+#pragma unroll
+            for (int c = 0; c < 5; c++) { in[c] = in1[c]; lv[c] = lv1[c]; }
+        }
+        __syncthreads();
+        // two rows per store instruction: each half-wave writes RS_S consecutive x of one row (256 B)
+        for (int r = 0; r < ny; r += 2)
+            if (r + half < ny && l32 < nx) out[(size_t)(y0 + r + half) * w + x0 + l32] = tile[l32][r + half];
+        __syncthreads();
     }
 }
 
@@ -685,8 +729,10 @@ void launch_blur_solve(hipStream_t s, const float *M, float *flow, int w, int h,
 void launch_blur_solve_running(hipStream_t s, const float *M, double *V, float *flow, int w, int h, int npairs, int winsize)
 {
     const int m = winsize / 2;
-    hipLaunchKernelGGL(k_vsum_running, dim3(cdiv(w, 256), 5, npairs), dim3(256), 0, s, M, V, w, h, m);
-    hipLaunchKernelGGL(k_hsum_running_solve, dim3(cdiv(h, 64), npairs), dim3(64), 0, s, V, reinterpret_cast<float2 *>(flow), w, h, m,
+    const size_t lds = sizeof(double) * RS_S * (RS_T + 1) + sizeof(float) * (size_t)(2 * m + 2) * RS_T;      // 16.6 KB + the M ring (4 KB at winsize 15, 33 KB at 127)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_vsum_running), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(k_vsum_running, dim3(cdiv(w, RS_T), 5, npairs), dim3(RS_T), lds, s, M, V, w, h, m);
+    hipLaunchKernelGGL(k_hsum_running_solve, dim3(cdiv(h, RS_T), npairs), dim3(RS_T), 0, s, V, reinterpret_cast<float2 *>(flow), w, h, m,
                        1. / ((double)winsize * winsize));
 }
 

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--winsize", type=int, default=15)
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--poly-n", type=int, default=5)
+    ap.add_argument("--box-order", type=int, default=0, help="1: the box window summed in OpenCV's literal order (verification mode)")
     a = ap.parse_args()
     import torch
     import hackathonopticalflow_amd as ofa
@@ -44,6 +45,8 @@ def main():
     v = torch.zeros_like(mask)
     eng = ofa.FarnebackEngine(a.w, a.h, a.batch, 0, levels=a.levels, iterations=a.iterations, winsize=a.winsize, flags=a.flags,
                               poly_n=a.poly_n, poly_sigma=1.2 if a.poly_n == 5 else 1.5)
+    if a.box_order:
+        eng.set_option("box_order", 1)
     st = torch.cuda.current_stream().cuda_stream
     run = lambda: eng.calc_batch_device(frames, 2 * a.batch, a.w, a.h, ofa.PAIRS_INDEPENDENT, flow,
                                         None if a.no_danger else mask, None if a.no_danger else v, stream=st)
