@@ -472,13 +472,18 @@ int ofarn_stage_blur_solve(ofarn_ctx *c, const float *h_M, int w, int h, float *
     std::vector<float> mp(npx * 5);
     for (size_t o = 0; o < npx; o++)
         for (int ch = 0; ch < 5; ch++) mp[ch * npx + o] = h_M[o * 5 + ch];     // interleaved -> planar
-    if ((rc = ws_reserve(c, 0, 0, 0, 0, npx * 5, 0))) return rc;
+    const bool gauss = (c->prm.flags & OFARN_FLAG_FARNEBACK_GAUSSIAN) != 0;
+    const bool running = c->box_running && !gauss;          // "box_order" = 1: the literal order; its double column sums sit in front of M
+    if ((rc = ws_reserve(c, 0, 0, 0, 0, npx * (running ? 15 : 5), 0))) return rc;
     if ((rc = begin_call(c, c->stream))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->ws[0].M, mp.data(), npx * 5 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    if (c->prm.flags & OFARN_FLAG_FARNEBACK_GAUSSIAN)
-        launch_gauss_solve(c->stream, c->ws[0].M, c->ws[0].flowA, w, h, 1, c->prm.winsize, c->d_gwin);
+    float *Mk = running ? c->ws[0].M + npx * 10 : c->ws[0].M;
+    HIP_TRY(hipMemcpyAsync(Mk, mp.data(), npx * 5 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (gauss)
+        launch_gauss_solve(c->stream, Mk, c->ws[0].flowA, w, h, 1, c->prm.winsize, c->d_gwin);
+    else if (running)
+        launch_blur_solve_running(c->stream, Mk, reinterpret_cast<double *>(c->ws[0].M), c->ws[0].flowA, w, h, 1, c->prm.winsize);
     else
-        launch_blur_solve(c->stream, c->ws[0].M, c->ws[0].flowA, w, h, 1, c->prm.winsize);
+        launch_blur_solve(c->stream, Mk, c->ws[0].flowA, w, h, 1, c->prm.winsize);
     HIP_TRY(hipMemcpyAsync(h_flow, c->ws[0].flowA, npx * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return end_call(c, c->stream);

@@ -53,6 +53,22 @@ for i in range(N):
         if not okb:
             bad += 1
             print("BATCH MISMATCH", w, h, kw, gs, flush=True)
+    # round 4: the same pair through ofarn_calc_reuse (a miss = one pair turn, then a hit after the roles are swapped back) and, every
+    # third case, in OpenCV's literal summation order ("box_order" = 1) against the oracle's OFO_BOX_RUNNING
+    with H.FarnebackEngine(w, h, 1, **kw) as eng:
+        g1 = eng.calc_reuse(a, b, None if init is None else init.copy())
+        g2 = eng.calc_reuse(b, a, None if init is None else init.copy())        # prev = the held frame: a hit
+        g3 = eng.calc_reuse(a, b, None if init is None else init.copy())        # again a hit
+        hits, misses = eng.reuse_info()
+        if not (np.array_equal(g1, got) and np.array_equal(g3, got) and (hits, misses) == (2, 1)):
+            bad += 1
+            print("REUSE MISMATCH", w, h, kw, hits, misses, flush=True)
+        if i % 3 == 2:
+            eng.set_option("box_order", 1)
+            lit = eng.calc(a, b, None if init is None else init.copy())
+            if not np.array_equal(lit, O.farneback(a, b, box_mode=O.BOX_RUNNING, init_flow=init, **kw)):
+                bad += 1
+                print("LITERAL-ORDER MISMATCH", w, h, kw, flush=True)
     if not np.array_equal(got_s, got):
         bad += 1
         print("STREAM MISMATCH", w, h, kw, float(np.abs(got_s - got).max()), flush=True)

@@ -101,6 +101,20 @@ def test_stage_blur_solve_bit_exact(H, oracle, w, h, winsize):
     np.testing.assert_array_equal(got, ref)
 
 
+@pytest.mark.parametrize("w,h,winsize", [(97, 83, 15), (200, 150, 2), (64, 130, 3), (333, 70, 10), (70, 333, 21), (150, 140, 63), (260, 200, 127),
+                                         (31, 5, 15), (5, 31, 15), (1, 1, 15), (65, 33, 4)])
+def test_stage_blur_solve_literal_order_bit_exact(H, oracle, w, h, winsize):
+    """FarnebackUpdateFlow_Blur alone in optflowgf.cpp's literal order (k_vsum_running + k_hsum_running_solve) on random matrices:
+    every window size class (even, odd, up to 127), images smaller than the window, tiles that do not divide the image."""
+    rng = np.random.default_rng(winsize * 1000 + w)
+    M = (rng.standard_normal((h, w, 5)) * 10).astype(np.float32)
+    z5, z2 = np.zeros((h, w, 5), np.float32), np.zeros((h, w, 2), np.float32)
+    ref, _ = oracle.update_flow_blur(z5, z5, z2, M, winsize, False, oracle.BOX_RUNNING)
+    with H.FarnebackEngine(w, h, 1, winsize=winsize) as eng:
+        eng.set_option("box_order", 1)
+        np.testing.assert_array_equal(eng.stage_blur_solve(M), ref)
+
+
 @pytest.mark.parametrize("sw,sh,dw,dh", [(160, 120, 320, 240), (60, 34, 120, 68), (120, 68, 240, 135), (49, 42, 97, 83)])
 def test_stage_flow_upsample_bit_exact(H, oracle, sw, sh, dw, dh):
     rng = np.random.default_rng(4)
