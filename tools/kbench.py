@@ -62,6 +62,16 @@ def main():
         print(f"{r['stage']:16s} L{r['level']} n={r['launches']:3d} avg={r['ms'] / r['launches']:8.4f} ms  "
               f"{r['units'] / r['launches'] / (r['ms'] / r['launches']) / 1e6:8.2f} Gunit/s")
     print(f"total {tot / a.reps:.3f} ms per pass of {a.batch} pairs -> {a.batch / (tot / a.reps) * 1e3:.1f} pairs/s")
+    # wall clock of the same passes with per-kernel timing off (kernels on internal streams overlap: the sum above then overstates)
+    eng.profile_enable(False)
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.reps
+    print(f"wall {dt * 1e3:.3f} ms per pass of {a.batch} pairs -> {a.batch / dt:.1f} pairs/s")
 
 
 if __name__ == "__main__":
