@@ -1095,29 +1095,6 @@ static void launch_flow_iter_m(hipStream_t s, const float *R, int fstep, const f
         hipLaunchKernelGGL((k_flow_iter<M_, 2>), grid, dim3(FI_THREADS), 0, s, R, fstep, fin, fout, w, h, strip_h, scale, up);
 }
 
-// Would launch_flow_iter run this level on the tile kernel (kernels_tile.hip)?  The same decision, for the host's schedule.
-template <int M_>
-static bool flow_iter_would_tile_m(int w, int h, int npairs, int winsize, int tile_mode)
-{
-    constexpr int OUTW = march_out_width(M_);
-    constexpr int B = 2 * M_ + 1;
-    const int nblk = (h + B - 1) / B;
-    const int strip_h = B * best_strip_units(nblk, B, B - 1, (int)cdivu(w, OUTW) * npairs, 3);
-    const long blocks = (long)cdivu(w, OUTW) * cdivu(h, strip_h) * npairs;
-    return flow_iter_tile_supported(winsize) && flow_iter_tile_preferred(blocks, tile_mode);
-}
-bool flow_iter_would_tile(int w, int h, int npairs, int winsize, int tile_mode)
-{
-    switch (winsize / 2) {
-    case 3: return flow_iter_would_tile_m<3>(w, h, npairs, winsize, tile_mode);
-    case 4: return flow_iter_would_tile_m<4>(w, h, npairs, winsize, tile_mode);
-    case 5: return flow_iter_would_tile_m<5>(w, h, npairs, winsize, tile_mode);
-    case 6: return flow_iter_would_tile_m<6>(w, h, npairs, winsize, tile_mode);
-    case 7: return flow_iter_would_tile_m<7>(w, h, npairs, winsize, tile_mode);
-    default: return false;
-    }
-}
-
 // mode 0: zero input flow; 1: upsample from coarse (up_* valid); 2: read flow_in.
 void launch_flow_iter(hipStream_t s, const float *R, int fstep, const float *flow_in, float *flow_out, int w,
                       int h, int npairs, int winsize, int mode, const float *coarse, int cw, int ch,

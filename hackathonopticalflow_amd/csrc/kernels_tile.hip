@@ -31,32 +31,10 @@ constexpr int TI_TW = OFARN_TILE_TW;
 #endif
 
 // One tile: output pixels [x0, x0 + TW) x [yb, yb + B) of pair p.  sM: matrices of padded rows yb .. yb+2B-2 at columns x0-m ..
-// x0+TW+m-1 (clamped); sV: column sums of the B output rows.  Called by the one-tile-per-block kernel below and, tile after tile, by
-// the persistent kernel that runs all iterations of the coarse levels in one launch (k_flow_levels_coop).
-// Flow accesses of the tile body.  COH = false: plain loads and stores (one launch per iteration: the kernel boundary orders them).
-// COH = true (k_flow_levels_coop): relaxed ATOMIC 8-byte loads and stores at agent scope -- the memory model's coherent accesses
-// (sc1: they neither hit a stale line of a CU's L1 / an XCD's L2 nor leave a dirty one behind), so that flow written by one block
-// before a device-wide barrier is what every other block reads behind it WITHOUT any cache write-back or invalidate at the barrier
-// (fences there cost 25 us per barrier issued by one thread per block and 130 us issued by all: measured, profiles/r04_coop_ab.txt).
-template <bool COH>
-__device__ __forceinline__ float2 ld_flow(const float2 *p)
-{
-    if (!COH) return *p;
-    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    float2 r;
-    r.x = __uint_as_float((unsigned)(v & 0xffffffffull));
-    r.y = __uint_as_float((unsigned)(v >> 32));
-    return r;
-}
-template <bool COH>
-__device__ __forceinline__ void st_flow(float2 *p, float2 v)
-{
-    if (!COH) { *p = v; return; }
-    const unsigned long long u = (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <int M_, int MODE, bool COH = false>   // MODE 0: flow_in == 0;  1: flow_in = upsample(coarse)*mul;  2: flow_in from HBM
+// x0+TW+m-1 (clamped); sV: column sums of the B output rows.  (A persistent kernel that called this body tile after tile for every
+// iteration of the coarse levels behind a device-wide barrier was built in round 4 and measured 40-50 us slower per 1080p turn than
+// the separate launches: git tag r04-coop-levels-experiment, profiles/r04_coop_ab.txt.)
+template <int M_, int MODE>   // MODE 0: flow_in == 0;  1: flow_in = upsample(coarse)*mul;  2: flow_in from HBM
 __device__ __forceinline__ void flow_iter_tile_body(float (&sM)[5][4 * M_ + 1][TI_TW + 2 * M_], double (&sV)[5][2 * M_ + 1][TI_TW + 2 * M_],
                                                     const float *__restrict__ R, int fstep, const float2 *__restrict__ flow_in,
                                                     float2 *__restrict__ flow_out, int w, int h, double scale, const UpsampleArgs &up,
@@ -90,7 +68,7 @@ __device__ __forceinline__ void flow_iter_tile_body(float (&sM)[5][4 * M_ + 1][T
         if (MODE == 2) {
             float2 f[PB];
 #pragma unroll
-            for (int q = 0; q < PB; q++) f[q] = ld_flow<COH>(&fin[(size_t)py[q] * w + px[q]]);
+            for (int q = 0; q < PB; q++) f[q] = fin[(size_t)py[q] * w + px[q]];
 #pragma unroll
             for (int q = 0; q < PB; q++) { dx[q] = f[q].x; dy[q] = f[q].y; }
         } else if (MODE == 1) {
@@ -104,8 +82,8 @@ __device__ __forceinline__ void flow_iter_tile_body(float (&sM)[5][4 * M_ + 1][T
                 int sy;
                 resize_coord(py[q], up.yscale, up.ch, sy, b1[q]);
                 const int sy1 = sy + 1 < up.ch ? sy + 1 : up.ch - 1;
-                p00[q] = ld_flow<COH>(&coarse[(size_t)sy * up.cw + sx]); p01[q] = ld_flow<COH>(&coarse[(size_t)sy * up.cw + sx1]);
-                p10[q] = ld_flow<COH>(&coarse[(size_t)sy1 * up.cw + sx]); p11[q] = ld_flow<COH>(&coarse[(size_t)sy1 * up.cw + sx1]);
+                p00[q] = coarse[(size_t)sy * up.cw + sx]; p01[q] = coarse[(size_t)sy * up.cw + sx1];
+                p10[q] = coarse[(size_t)sy1 * up.cw + sx]; p11[q] = coarse[(size_t)sy1 * up.cw + sx1];
             }
 #pragma unroll
             for (int q = 0; q < PB; q++) {
@@ -176,7 +154,7 @@ __device__ __forceinline__ void flow_iter_tile_body(float (&sM)[5][4 * M_ + 1][T
         float2 o;
         o.x = (float)((g[0] * g[4] - g[1] * g[3]) * idet);
         o.y = (float)((g[2] * g[3] - g[1] * g[4]) * idet);
-        st_flow<COH>(&flow_out[p * npx + (size_t)gy * w + gx], o);
+        flow_out[p * npx + (size_t)gy * w + gx] = o;
     }
 }
 
@@ -188,101 +166,6 @@ __global__ __launch_bounds__(256) void k_flow_iter_tile(const float *__restrict_
     __shared__ float sM[5][NT][IW];
     __shared__ double sV[5][B][IW];
     flow_iter_tile_body<M_, MODE>(sM, sV, R, fstep, flow_in, flow_out, w, h, scale, up, blockIdx.x * TI_TW, blockIdx.y * B, blockIdx.z);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_flow_levels_coop: EVERY iteration of several consecutive pyramid levels of ONE pair in one launch (round 4, VERDICT r3 next #4a).
-// A 1080p pair's levels 2-5 are 288, 72, 20 and 6 tiles; as twelve separate launches they cost 7-11 us each on a mostly idle chip,
-// most of it launch-to-launch latency, plus 12-16 us wherever a level's first iteration waits on an event.  Here a persistent grid
-// (all blocks co-resident: the host sizes it from the occupancy query) walks the same (level, iteration) sequence, a device-wide
-// barrier between steps: arrive = one atomic add per block on a counter in HBM, wait = poll until the counter reaches this step's
-// target (the launch's base + step * blocks; the counter only grows, so no reset between launches); the flow that crosses a barrier
-// is written and read with coherent (agent-scope atomic) accesses, so the barrier itself does no cache maintenance.  Same tile body, same buffers
-// and ping-pong order as the separate launches: bit-identical.  The wait is BOUNDED: a block that has polled for longer than
-// `timeout_ticks` of the 100 MHz wall clock raises *fail and leaves, every other block leaves at its next poll -- results are then
-// undefined, the host sees the flag after its synchronisation, reruns the levels with separate launches and stops using this kernel
-// on the context (a grid that is not fully resident -- a shared GPU -- cannot deadlock the device).
-// ---------------------------------------------------------------------------------------------
-// The barrier, split in its two halves.  arrive: one relaxed atomic add per ACTIVE block (a block that had a tile in the step) on a
-// counter in HBM, once the block's (coherent) flow stores have completed.  wait: thread 0 polls the counter until it reaches the
-// cumulative number of arrivals of all steps so far; a block with no tile in the next step does not wait for it at all (the counter
-// only grows, so waiting later for a later target covers it) -- a 6-tile level costs 6 arrivals, not one per block of the grid.
-// bar[0] = arrivals, bar[1] = the give-up flag the blocks poll now and then (device memory: polling the host-visible copy over PCIe
-// from every block cost 115 us per barrier); *fail_host is only WRITTEN, by the block that gives up.
-__device__ __forceinline__ void coop_arrive(unsigned long long *bar)
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's stores have completed (s_waitcnt vmcnt(0))
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ bool coop_wait(unsigned long long *bar, unsigned long long target, unsigned *fail_host, unsigned long long timeout_ticks)
-{
-    __shared__ int s_ok;
-    if (threadIdx.x == 0) {
-        int ok = 1;
-        unsigned long long t0 = 0;
-        for (unsigned n = 0; __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; n++) {
-            if ((n & 15u) != 15u) continue;
-            __builtin_amdgcn_s_sleep(2);
-            if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) { ok = 0; break; }
-            const unsigned long long t = wall_clock64();
-            if (t0 == 0) t0 = t;
-            else if (t - t0 > timeout_ticks) {
-                __hip_atomic_store(bar + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(fail_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                ok = 0;
-                break;
-            }
-        }
-        s_ok = ok;
-    }
-    __syncthreads();
-    return s_ok != 0;
-}
-
-template <int M_>
-__global__ __launch_bounds__(256) void k_flow_levels_coop(CoopArgs a)
-{
-    constexpr int B = 2 * M_ + 1, IW = TI_TW + 2 * M_, NT = 2 * B - 1;
-    __shared__ float sM[5][NT][IW];
-    __shared__ double sV[5][B][IW];
-    const float *prev = a.prev;            // final flow of the level above (nullptr: the first level here is the coarsest)
-    int pw = a.pw, ph = a.ph;
-    unsigned long long arrivals = a.base;  // what the counter reads once every step so far has been finished by all its blocks
-    bool behind = false;                   // this block has not yet waited for the steps before the current one
-    for (int li = 0; li < a.nlev; li++) {
-        const CoopLevel &L = a.lv[li];
-        const float *cur = (li == 0 && !prev) ? a.init : nullptr;
-        const int tx = (L.w + TI_TW - 1) / TI_TW, ty = (L.h + B - 1) / B, ntiles = tx * ty;
-        const bool active = (int)blockIdx.x < ntiles;
-        const unsigned long long act = (unsigned long long)min(ntiles, (int)gridDim.x);
-        for (int it = 0; it < a.iterations; it++) {
-            // the buffer walk of run_wave: the coarse flow is only read by iteration 0
-            const float *busy = (it == 0 && prev) ? prev : cur;
-            float *out = (it == a.iterations - 1 && li == a.nlev - 1 && a.final_out) ? a.final_out : (busy == a.flowA ? a.flowB : a.flowA);
-            const int mode = it == 0 ? (prev ? 1 : (cur ? 2 : 0)) : 2;
-            if (active) {
-                if (behind && !coop_wait(a.bar, arrivals, a.fail, a.timeout_ticks)) return;
-                behind = false;
-                UpsampleArgs up{reinterpret_cast<const float2 *>(prev), pw, ph, L.xofs, L.xa, ph > 0 ? 1. / ((double)L.h / ph) : 1., a.mul, nullptr};
-                const float2 *fin = reinterpret_cast<const float2 *>(cur);
-                float2 *fout = reinterpret_cast<float2 *>(out);
-                for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-                    const int by = t / tx, bx = t - by * tx;
-                    if (mode == 0) flow_iter_tile_body<M_, 0, true>(sM, sV, L.R, L.fstep, fin, fout, L.w, L.h, a.scale, up, bx * TI_TW, by * B, 0);
-                    else if (mode == 1) flow_iter_tile_body<M_, 1, true>(sM, sV, L.R, L.fstep, fin, fout, L.w, L.h, a.scale, up, bx * TI_TW, by * B, 0);
-                    else flow_iter_tile_body<M_, 2, true>(sM, sV, L.R, L.fstep, fin, fout, L.w, L.h, a.scale, up, bx * TI_TW, by * B, 0);
-                    __syncthreads();          // sM / sV are reused by the block's next tile
-                }
-                if (!(li == a.nlev - 1 && it == a.iterations - 1)) coop_arrive(a.bar);      // nobody waits behind the last step
-            }
-            cur = out;
-            arrivals += act;
-            behind = true;
-        }
-        prev = cur; pw = L.w; ph = L.h;
-    }
 }
 
 // Instantiated for the window half-widths whose two LDS arrays fit 64 KB: m = 3 .. 7 (winsize 6 .. 15).
@@ -319,41 +202,6 @@ static void launch_flow_iter_tile_m(hipStream_t s, const float *R, int fstep, co
         hipLaunchKernelGGL((k_flow_iter_tile<M_, 1>), grid, dim3(256), 0, s, R, fstep, fin, fout, w, h, scale, up);
     else
         hipLaunchKernelGGL((k_flow_iter_tile<M_, 2>), grid, dim3(256), 0, s, R, fstep, fin, fout, w, h, scale, up);
-}
-
-// Blocks of k_flow_levels_coop<m> that are resident at once on the current device (0: not instantiated for this window).
-int flow_levels_coop_capacity(int winsize)
-{
-    int per_cu = 0;
-    hipError_t e = hipErrorInvalidValue;
-    switch (winsize / 2) {
-    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_flow_levels_coop<3>, 256, 0); break;
-    case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_flow_levels_coop<4>, 256, 0); break;
-    case 5: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_flow_levels_coop<5>, 256, 0); break;
-    case 6: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_flow_levels_coop<6>, 256, 0); break;
-    case 7: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_flow_levels_coop<7>, 256, 0); break;
-    default: return 0;
-    }
-    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
-    return per_cu * march_cu_count();
-}
-
-int flow_levels_coop_tiles(int w, int h, int winsize)
-{
-    const int B = 2 * (winsize / 2) + 1;
-    return ((w + TI_TW - 1) / TI_TW) * ((h + B - 1) / B);
-}
-
-void launch_flow_levels_coop(hipStream_t s, const CoopArgs &a, int winsize, int blocks)
-{
-    switch (winsize / 2) {
-    case 3: hipLaunchKernelGGL(k_flow_levels_coop<3>, dim3(blocks), dim3(256), 0, s, a); break;
-    case 4: hipLaunchKernelGGL(k_flow_levels_coop<4>, dim3(blocks), dim3(256), 0, s, a); break;
-    case 5: hipLaunchKernelGGL(k_flow_levels_coop<5>, dim3(blocks), dim3(256), 0, s, a); break;
-    case 6: hipLaunchKernelGGL(k_flow_levels_coop<6>, dim3(blocks), dim3(256), 0, s, a); break;
-    case 7: hipLaunchKernelGGL(k_flow_levels_coop<7>, dim3(blocks), dim3(256), 0, s, a); break;
-    default: break;
-    }
 }
 
 void launch_flow_iter_tile(hipStream_t s, const float *R, int fstep, const float *flow_in, float *flow_out, int w, int h,

@@ -378,59 +378,8 @@ void plan_wave(const ofarn_ctx *c, const uint8_t *d_frames, int nframes, int w, 
 
 // One wave: npairs <= max_batch pairs, frames already in HBM.
 // d_init (OPTFLOW_USE_INITIAL_FLOW): full-resolution start flows float[npairs][h][w][2]; may alias d_flow.
-bool coop_gave_up(ofarn_ctx *c)
-{
-    if (!c->coop_fail || *reinterpret_cast<volatile unsigned *>(c->coop_fail) == 0u) return false;
-    *c->coop_fail = 0;
-    c->coop_levels = 0;
-    c->coop_base = 0;
-    c->coop_fallbacks++;
-    if (c->coop_bar) (void)hipMemset(c->coop_bar, 0, 2 * sizeof(unsigned long long));
-    return true;
-}
-
-// Levels nlev .. kmin (coarse -> fine) that one cooperative launch may take in this wave; returns kmin, or nlev + 1 for none.
-// Streaming turns only: there every level has R slots of its own, so the expansions of all levels can be finished before the
-// launch (a batch wave reuses ONE R buffer level after level).
-static int coop_level_range(ofarn_ctx *c, int npairs, bool streaming, int *blocks)
-{
-    const int nlev = (int)c->lv.size() - 1;
-    *blocks = 0;
-    if (!c->coop_now || !streaming || c->coop_levels <= 0 || npairs != 1 || c->prof_on || c->force_generic || c->prm.iterations < 1 ||
-        (c->prm.flags & OFARN_FLAG_FARNEBACK_GAUSSIAN) || !flow_iter_tile_supported(c->prm.winsize))
-        return nlev + 1;
-    if (c->coop_capacity < 0) c->coop_capacity = flow_levels_coop_capacity(c->prm.winsize);
-    if (c->coop_capacity < 1) return nlev + 1;
-    if (!c->coop_bar) {
-        if (hipMalloc((void **)&c->coop_bar, 256) != hipSuccess) { (void)hipGetLastError(); c->coop_bar = nullptr; return nlev + 1; }
-        if (hipMemset(c->coop_bar, 0, 256) != hipSuccess ||
-            hipHostMalloc((void **)&c->coop_fail, 64, hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            (void)hipFree(c->coop_bar);
-            c->coop_bar = nullptr; c->coop_fail = nullptr;
-            return nlev + 1;
-        }
-        *c->coop_fail = 0;
-    }
-    int kmin = nlev + 1, maxtiles = 0;
-    for (int k = nlev; k >= 0 && nlev - k < 8; k--) {
-        const Level &L = c->lv[k];
-        if (!flow_iter_would_tile(L.w, L.h, 1, c->prm.winsize, c->tile_mode)) break;
-        const int tiles = flow_levels_coop_tiles(L.w, L.h, c->prm.winsize);
-        if (c->coop_levels == 1 && tiles > c->coop_capacity) break;
-        kmin = k;
-        maxtiles = std::max(maxtiles, tiles);
-    }
-    if (kmin > nlev) return kmin;
-    if ((nlev - kmin + 1) * c->prm.iterations < 2) return nlev + 1;      // a single step: nothing to merge
-    const int rounds = (maxtiles + c->coop_capacity - 1) / c->coop_capacity;
-    *blocks = (maxtiles + rounds - 1) / rounds;
-    return kmin;
-}
-
 int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, int pairs_mode, int w,
-             int h, float *d_flow, uint8_t *d_mask, uint8_t *d_v, int wi, const float *d_init, ofarn_ctx::Stream *st, bool skip_ab,
-             bool st_pair)
+             int h, float *d_flow, uint8_t *d_mask, uint8_t *d_v, int wi, const float *d_init, ofarn_ctx::Stream *st, bool st_pair)
 {
     ofarn_ctx::Workspace &ws = c->ws[wi];
     // streaming turn: one new frame into slot `snew`; the pair is (slot cur, slot snew), one pair
@@ -479,10 +428,7 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
     // that level's first iteration.  The critical path is then stages A + B of the COARSEST level + the iterations, not all of
     // A + B.  Possible here because every level has its own R slots (a batch wave reuses one R buffer level after level);
     // ws.tmp / ws.I are only touched by the A + B chain, which stays on one stream.  Per-kernel timing keeps one stream.
-    c->coop_used = false;
-    int coop_blocks = 0;
-    const int coop_kmin = (iterate && fused) ? coop_level_range(c, npairs, st != nullptr, &coop_blocks) : nlev + 1;   // levels nlev .. coop_kmin in one launch
-    const bool overlap = st && iterate && !skip_ab && !c->prof_on && c->stream_overlap && c->aux[0] && c->ev_fork;
+    const bool overlap = st && iterate && !c->prof_on && c->stream_overlap && c->aux[0] && c->ev_fork;
     hipStream_t sab = overlap ? c->aux[0] : s;
     if (overlap) {
         for (int k = 0; k <= nlev; k++)
@@ -491,7 +437,7 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
         HIP_TRY(hipEventRecord(c->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(sab, c->ev_fork, 0));
     }
-    if (multi && !skip_ab) {
+    if (multi) {
         for (int k = 0; k <= nlev; k++) if (has_tmp[k]) tmp_of[k] = ws.tmp + wp.tmp_off[k];
         for (int i = 0; i < HL.n; i++) HL.lv[i].dst = tmp_of[wp.hl_level[i]];
         if (HL.n > 0) {
@@ -527,9 +473,7 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
     bool sync_at[32];
     for (int k = 0; k <= nlev; k++) sync_at[k] = c->stream_overlap < 2 || k == nlev || k == 0 || ((nlev - k) % 2 == 1);
     int waited = nlev + 1;           // the chain has waited for the event behind this level (and so for every level above it)
-    // two passes also without the side stream when a cooperative launch is coming: it needs the expansions of ALL its levels first
-    const bool two_pass = overlap || (coop_kmin <= nlev && !skip_ab);
-    const int npass = two_pass ? 2 : 1;
+    const int npass = overlap ? 2 : 1;
     for (int pass = 0; pass < npass; pass++)
     for (int k = nlev; k >= 0; k--) {
         const Level &L = c->lv[k];
@@ -539,14 +483,10 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
         // stages A + B: level image and polynomial expansion of every frame of the wave
         const bool march = !c->force_generic && polyexp_march_supported(c->prm.poly_n);
         const bool lds_ok = (size_t)(w + 2 * (L.ksize / 2)) * 4 * 33 / 32 + 4 * (size_t)L.ksize + 64 <= 60 * 1024;
-        if (skip_ab) {
-            // redo of the iterations only (a cooperative launch gave up): the expansions of both frames are where they were
-        } else if (two_pass && pass == 1) {
-            // the chain: wait for the event that covers this level -- the nearest one recorded at or below it; a cooperative launch
-            // starting at this level needs the expansions of every level down to coop_kmin
-            const int need = (k == nlev && coop_kmin <= nlev) ? coop_kmin : k;
-            if (overlap && iterate && waited > need) {
-                int e = need;
+        if (overlap && pass == 1) {
+            // the chain: wait for the event that covers this level -- the nearest one recorded at or below it
+            if (iterate && waited > k) {
+                int e = k;
                 while (!sync_at[e]) e--;             // sync_at[0] is always set
                 HIP_TRY(hipStreamWaitEvent(s, c->ev_level[e], 0));
                 waited = e;
@@ -584,51 +524,8 @@ int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, i
             });
         }
         if (!iterate) continue;      // streaming, first frame: nothing to pair it with yet
-        if (two_pass && pass == 0) {
-            if (overlap && sync_at[k]) HIP_TRY(hipEventRecord(c->ev_level[k], sab));
-            continue;
-        }
-        if (fused && k >= coop_kmin && k < nlev) {
-            // this level's iterations ran inside the cooperative launch issued at level nlev
-            continue;
-        }
-        if (fused && k == nlev && coop_kmin <= nlev) {
-            // every iteration of levels nlev .. coop_kmin in ONE launch (k_flow_levels_coop): the buffer walk below, done on the device
-            CoopArgs a{};
-            a.nlev = nlev - coop_kmin + 1;
-            a.iterations = c->prm.iterations;
-            for (int q = nlev; q >= coop_kmin; q--) {
-                const Level &Lq = c->lv[q];
-                a.lv[nlev - q] = CoopLevel{R_it(q), fstep, Lq.w, Lq.h, Lq.d_fxofs, Lq.d_fxa};
-            }
-            float *cfA = ws.flowA, *cfB = ws.flowB;
-            a.flowA = cfA; a.flowB = cfB;
-            a.init = init_cur;
-            a.prev = nullptr; a.pw = 0; a.ph = 0;
-            a.final_out = (coop_kmin == 0 && d_flow) ? d_flow : nullptr;
-            a.mul = mul;
-            a.scale = 1. / ((double)c->prm.winsize * c->prm.winsize);
-            a.bar = c->coop_bar; a.base = c->coop_base; a.fail = c->coop_fail;
-            a.timeout_ticks = 5000000ull;                     // 50 ms of the 100 MHz wall clock per wait
-            launch_flow_levels_coop(s, a, c->prm.winsize, coop_blocks);
-            // what the arrival counter will read when the launch has finished: every step but the last adds its active blocks
-            for (int q = nlev; q >= coop_kmin; q--) {
-                const unsigned long long act = (unsigned long long)std::min(flow_levels_coop_tiles(c->lv[q].w, c->lv[q].h, c->prm.winsize), coop_blocks);
-                c->coop_base += act * (unsigned long long)(c->prm.iterations - (q == coop_kmin ? 1 : 0));
-            }
-            c->coop_used = true;
-            c->coop_launches++;
-            // where the device's buffer walk ends: replay it on the host (pointers only)
-            const float *pv = nullptr;
-            for (int q = nlev; q >= coop_kmin; q--) {
-                const float *cur = q == nlev ? init_cur : nullptr;
-                for (int i = 0; i < c->prm.iterations; i++) {
-                    const float *busy = (i == 0 && pv) ? pv : cur;
-                    cur = (i == c->prm.iterations - 1 && q == 0 && d_flow) ? d_flow : (busy == cfA ? cfB : cfA);
-                }
-                pv = cur;
-            }
-            prev = const_cast<float *>(pv); pw = c->lv[coop_kmin].w; ph = c->lv[coop_kmin].h;
+        if (overlap && pass == 0) {
+            if (sync_at[k]) HIP_TRY(hipEventRecord(c->ev_level[k], sab));
             continue;
         }
         if (fused) {
@@ -844,7 +741,6 @@ int ofarn_create(const ofarn_params *params, int device, int max_w, int max_h, i
     if (const char *e = getenv("OFARN_TILE")) c->tile_mode = e[0] != '0';
     if (const char *e = getenv("OFARN_STREAM_ZERO_COPY")) c->stream_zero_copy = e[0] != '0';
     if (const char *e = getenv("OFARN_BOX_ORDER")) c->box_running = e[0] == '1';
-    if (const char *e = getenv("OFARN_COOP_LEVELS")) c->coop_levels = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
     if (!poly_prepare(params->poly_n, params->poly_sigma, c->poly)) {
         delete c;
         return fail(OFARN_E_INVALID, "poly_n out of range");
@@ -899,8 +795,6 @@ void ofarn_destroy(ofarn_ctx *c)
         for (float *p : {ws.tmp, ws.I, ws.R, ws.M, ws.flowA, ws.flowB}) if (p) (void)hipFree(p);
     if (c->st_flow) (void)hipFree(c->st_flow);
     if (c->d_gwin) (void)hipFree(c->d_gwin);
-    if (c->coop_bar) (void)hipFree(c->coop_bar);
-    if (c->coop_fail) (void)hipHostFree(c->coop_fail);
     {
         ofarn_ctx::Stream &st = c->stream_state;
         if (st.copy_stream) { (void)hipStreamSynchronize(st.copy_stream); (void)hipStreamDestroy(st.copy_stream); }
@@ -952,14 +846,6 @@ int ofarn_set_option(ofarn_ctx *c, const char *name, int value)
     else if (n == "debug_fail_wave") c->debug_fail_wave = value;
     else if (n == "prof_dual") c->prof_dual = value != 0;
     else if (n == "box_order") c->box_running = value != 0;
-    else if (n == "coop_levels") c->coop_levels = value < 0 ? 0 : (value > 2 ? 2 : value);
-    else if (n == "debug_coop_fail") {       // test hook: as if a wait had given up (the flag the blocks poll + the one the host reads)
-        if (c->coop_fail && c->coop_bar) {
-            const unsigned long long f = value ? 1ull : 0ull;
-            HIP_TRY(hipMemcpy(c->coop_bar + 1, &f, sizeof f, hipMemcpyHostToDevice));
-            *c->coop_fail = value ? 1u : 0u;
-        }
-    }
     else return fail(OFARN_E_INVALID, "unknown option '%s'", name);
     return OFARN_OK;
 }

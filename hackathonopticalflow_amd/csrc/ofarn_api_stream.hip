@@ -111,7 +111,7 @@ int stream_turn(ofarn_ctx *c, hipStream_t s, const uint8_t *d_gray, int w, int h
     const bool had = st.have || pair;
     const bool use_init = (c->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW) != 0;
     int rc = run_wave(c, s, d_gray, 1, OFARN_PAIRS_CONSECUTIVE, w, h, d_flow, had ? d_mask : nullptr, had ? d_v : nullptr, 0,
-                      (use_init && had) ? d_flow : nullptr, &st, false, pair);
+                      (use_init && had) ? d_flow : nullptr, &st, pair);
     if (rc) {
         st.have = false;                         // a half-written slot must not be paired with anything
         if (c->aux[0]) (void)hipStreamSynchronize(c->aux[0]);   // stages A + B may have been left running beside the caller's stream
@@ -123,21 +123,6 @@ int stream_turn(ofarn_ctx *c, hipStream_t s, const uint8_t *d_gray, int w, int h
     st.view_flow_valid = had && d_flow == c->st_flow && d_flow != nullptr;
     st.view_danger_valid = st.view_bgr_valid = false;      // ofarn_stream_next_view sets them behind its own turn
     return had ? OFARN_OK : OFARN_STREAM_PRIMED;
-}
-
-// A cooperative launch of the turn that just ended gave up a wait (the flag is read behind the entry point's synchronisation): the
-// turn's iterations are run again with separate launches -- the expansions of both frames are still in their slots -- and the call
-// synchronises again.  The context has stopped using cooperative launches by then (coop_gave_up).
-int stream_redo_iterations(ofarn_ctx *c, hipStream_t s, int w, int h, float *d_flow, uint8_t *d_mask, uint8_t *d_v)
-{
-    ofarn_ctx::Stream &st = c->stream_state;
-    st.cur ^= 1;                                   // as it was when the turn was enqueued
-    const bool use_init = (c->prm.flags & OFARN_FLAG_USE_INITIAL_FLOW) != 0;
-    const int rc = run_wave(c, s, st.d_frame, 1, OFARN_PAIRS_CONSECUTIVE, w, h, d_flow, d_mask, d_v, 0, use_init ? d_flow : nullptr, &st, true);
-    st.cur ^= 1;
-    if (rc) { st.have = false; return rc; }
-    HIP_TRY(hipStreamSynchronize(s));
-    return OFARN_OK;
 }
 
 int stream_check(ofarn_ctx *c, int w, int h, hipStream_t s = nullptr, bool device_entry = false)
@@ -250,26 +235,17 @@ static int stream_next_host(ofarn_ctx *c, const uint8_t *h_frame, int bgr, int w
             direct = true;
         }
     }
-    c->coop_now = !use_init;       // synchronous entry point: the flag a cooperative launch may raise is looked at below
     const int turn = stream_turn(c, s, st.d_frame, w, h, d_out, h_mask ? c->st_mask : nullptr, h_mask ? c->st_v : nullptr);
-    c->coop_now = false;
     if (turn < 0) { (void)end_call(c, s); return turn; }
     HIP_TRY(hipEventRecord(c->ev1, s));
-    auto copy_back = [&]() -> int {
+    if (turn == OFARN_OK) {
         if (!direct) HIP_TRY(hipMemcpyAsync(h_flow, c->st_flow, fsz * 2 * sizeof(float), hipMemcpyDeviceToHost, s));
         if (h_mask && c->P > 0) {
             HIP_TRY(hipMemcpyAsync(h_mask, c->st_mask, c->P, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(h_v, c->st_v, c->P, hipMemcpyDeviceToHost, s));
         }
-        return OFARN_OK;
-    };
-    if (turn == OFARN_OK && (rc = copy_back())) return rc;
-    HIP_TRY(hipStreamSynchronize(s));
-    if (turn == OFARN_OK && c->coop_used && coop_gave_up(c)) {
-        if ((rc = stream_redo_iterations(c, s, w, h, d_out, h_mask ? c->st_mask : nullptr, h_mask ? c->st_v : nullptr)) ||
-            (rc = copy_back())) { (void)end_call(c, s); return rc; }
-        HIP_TRY(hipStreamSynchronize(s));
     }
+    HIP_TRY(hipStreamSynchronize(s));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last_ms = ms;
@@ -374,9 +350,7 @@ int ofarn_calc_reuse(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next,
         HIP_TRY(hipMemcpyAsync(st.d_frame + (both ? fsz : 0), next_kept ? st.h_keep[kn] : h_next, fsz, hipMemcpyHostToDevice, s));
         if (use_init) HIP_TRY(hipMemcpyAsync(c->st_flow, h_flow, flow_bytes, hipMemcpyHostToDevice, s));
         HIP_TRY(hipEventRecord(c->ev0, s));
-        c->coop_now = !use_init;
         const int turn = stream_turn(c, s, st.d_frame, w, h, d_out, nullptr, nullptr, both);
-        c->coop_now = false;
         if (turn < 0) return turn;
         if (turn != OFARN_OK) return fail(OFARN_E_HIP, "internal: the session held no frame to pair with");
         HIP_TRY(hipEventRecord(c->ev1, s));
@@ -402,12 +376,6 @@ int ofarn_calc_reuse(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next,
         st.reuse_misses++;
     } else st.reuse_hits++;
     if (hipStreamSynchronize(s) != hipSuccess) return give_up(fail(OFARN_E_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(hipGetLastError())));
-    if (c->coop_used && coop_gave_up(c)) {
-        // (an optimistic turn that was thrown away may have raised the flag too: the last turn is simply run again)
-        if ((rc = stream_redo_iterations(c, s, w, h, d_out, nullptr, nullptr))) return give_up(rc);
-        if (!direct && hipMemcpy(h_flow, c->st_flow, flow_bytes, hipMemcpyDeviceToHost) != hipSuccess)
-            return give_up(fail(OFARN_E_HIP, "hipMemcpy failed: %s", hipGetErrorString(hipGetLastError())));
-    }
     float ms = 0;
     if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms; else (void)hipGetLastError();
     st.keep_cur = kn;
@@ -415,14 +383,6 @@ int ofarn_calc_reuse(ofarn_ctx *c, const uint8_t *h_prev, const uint8_t *h_next,
     st.keep_turn = st.turns;
     if (reused) *reused = reuse ? 1 : 0;
     return end_call(c, s);
-}
-
-int ofarn_coop_info(const ofarn_ctx *c, unsigned long long *launches, unsigned long long *fallbacks)
-{
-    if (!c) return fail(OFARN_E_INVALID, "ctx is NULL");
-    if (launches) *launches = c->coop_launches;
-    if (fallbacks) *fallbacks = c->coop_fallbacks;
-    return OFARN_OK;
 }
 
 int ofarn_calc_reuse_info(const ofarn_ctx *c, unsigned long long *hits, unsigned long long *misses)
@@ -501,17 +461,13 @@ int ofarn_stream_next_view(ofarn_ctx *c, const uint8_t *h_frame, int bgr, int w,
     HIP_TRY(hipEventRecord(c->ev0, s));
     if (bgr)
         timed(c, s, OFARN_STAGE_BGR2GRAY, 0, (double)fsz, [&] { launch_bgr2gray(s, st.d_bgr, st.d_frame, fsz, kGrayB, kGrayG, kGrayR, kGrayShift); });
-    auto consumers = [&]() -> int {
+    const int turn = stream_turn(c, s, st.d_frame, w, h, c->st_flow, P ? d_mask : nullptr, P ? d_v : nullptr);
+    if (turn < 0) { (void)end_call(c, s); return turn; }
+    if (turn == OFARN_OK) {
         if (h_lines && K > 0) launch_flow_arrows(s, c->st_flow, w, h, 1, nx, ny, astart, (double)arrow_step, d_lines);
         if (h_rainbow) launch_flow_hsv(s, c->st_flow, fsz, nullptr, d_rb);
         HIP_TRY(hipGetLastError());
-        return OFARN_OK;
-    };
-    c->coop_now = true;
-    const int turn = stream_turn(c, s, st.d_frame, w, h, c->st_flow, P ? d_mask : nullptr, P ? d_v : nullptr);
-    c->coop_now = false;
-    if (turn < 0) { (void)end_call(c, s); return turn; }
-    if (turn == OFARN_OK && (rc = consumers())) return rc;
+    }
     if (turn == OFARN_OK) {
         st.view_danger_valid = P > 0;
         st.view_mask_off = lines_bytes;
@@ -519,18 +475,11 @@ int ofarn_stream_next_view(ofarn_ctx *c, const uint8_t *h_frame, int bgr, int w,
         st.view_bgr_valid = bgr != 0;
     }
     HIP_TRY(hipEventRecord(c->ev1, s));
-    auto fetch = [&]() -> int {
+    if (turn == OFARN_OK) {
         if (small) HIP_TRY(hipMemcpyAsync(st.h_view, st.d_view, small, hipMemcpyDeviceToHost, s));
         if (h_rainbow) HIP_TRY(hipMemcpyAsync(h_rainbow, d_rb, rb_bytes, hipMemcpyDeviceToHost, s));
-        return OFARN_OK;
-    };
-    if (turn == OFARN_OK && (rc = fetch())) return rc;
-    HIP_TRY(hipStreamSynchronize(s));
-    if (turn == OFARN_OK && c->coop_used && coop_gave_up(c)) {
-        if ((rc = stream_redo_iterations(c, s, w, h, c->st_flow, P ? d_mask : nullptr, P ? d_v : nullptr)) || (rc = consumers()) ||
-            (rc = fetch())) { (void)end_call(c, s); return rc; }
-        HIP_TRY(hipStreamSynchronize(s));
     }
+    HIP_TRY(hipStreamSynchronize(s));
     if (turn == OFARN_OK) {
         if (h_lines && K > 0) memcpy(h_lines, st.h_view, lines_bytes);
         if (P) { memcpy(h_mask, st.h_view + lines_bytes, P); memcpy(h_v, st.h_view + lines_bytes + P, P); }

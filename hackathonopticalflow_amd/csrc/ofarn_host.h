@@ -194,19 +194,6 @@ struct ofarn_ctx {
     hipEvent_t ev_level[32] = {nullptr};
     int push_blocks = 0;                // ofarn_stream_submit: > 0 pushes a finished flow field to pinned host memory with a kernel of that many
                                         // blocks instead of hipMemcpyAsync ("push_blocks"; measured slower at every size, kept as an experiment)
-    // Cooperative launch of the coarse levels of a single pair (k_flow_levels_coop; "coop_levels": 0 = off, the DEFAULT: measured
-    // 40-50 us SLOWER per 1080p turn than the twelve separate launches it replaces (profiles/r04_coop_ab.txt) -- a device-wide
-    // barrier on this 8-XCD part costs as much as a kernel boundary; 1 = the levels whose tiles are all resident at once, 2 = every
-    // level that takes the tile kernel).  Only host-synchronous entry points use it (coop_now): they look at *coop_fail behind
-    // their synchronisation and redo the levels with separate launches if a wait gave up.
-    int coop_levels = 0;
-    bool coop_now = false;              // set by a host-synchronous entry point around run_wave
-    bool coop_used = false;             // the most recent run_wave took the cooperative launch
-    unsigned long long *coop_bar = nullptr;   // device
-    unsigned long long coop_base = 0;
-    unsigned *coop_fail = nullptr;      // page-locked host memory
-    int coop_capacity = -1;             // co-resident blocks (-1: not queried yet)
-    unsigned long long coop_launches = 0, coop_fallbacks = 0;
     int stream_zero_copy = 1;           // ofarn_stream_next: let the last kernel write a pinned flow buffer itself (OFARN_STREAM_ZERO_COPY=0: copy)
     // host-API staging (lazy)
     uint8_t *st_frames = nullptr;
@@ -274,10 +261,7 @@ int end_call(ofarn_ctx *c, hipStream_t s);
 // polynomial expansions go to the free slot of st->R, and -- if a previous frame is held -- the pair (previous, new) is iterated.
 int run_wave(ofarn_ctx *c, hipStream_t s, const uint8_t *d_frames, int npairs, int pairs_mode, int w, int h, float *d_flow,
              uint8_t *d_mask, uint8_t *d_v, int wi = 0, const float *d_init = nullptr, ofarn_ctx::Stream *st = nullptr,
-             bool skip_ab = false, bool st_pair = false);
-// Behind a host-synchronous entry point's synchronisation: did a cooperative launch give up a wait?  If so the context stops using
-// cooperative launches, the barrier state is reset and true is returned (the caller reruns the iterations).
-bool coop_gave_up(ofarn_ctx *c);
+             bool st_pair = false);
 
 // Runs `launch` and, when profiling is on, brackets it with two events on the same stream.
 template <typename F>

@@ -72,34 +72,6 @@ bool flow_iter_tile_preferred(long marching_blocks, int tile_mode);
 void launch_flow_iter_tile(hipStream_t s, const float *R, int fstep, const float *flow_in, float *flow_out, int w, int h,
                            int npairs, int winsize, int mode, const float *coarse, int cw, int ch, const int *d_xofs,
                            const float *d_xa, float mul);
-// All iterations of several consecutive levels of ONE pair in a single launch behind a bounded device-wide barrier
-// (kernels_tile.hip, k_flow_levels_coop): the latency form of the coarse levels of a single pair.  Levels coarse -> fine.
-struct CoopLevel {
-    const float *R;      // level's R base as launch_flow_iter takes it (streaming: slot `cur`), with fstep
-    int fstep;
-    int w, h;
-    const int *xofs;     // flow resize tables of THIS level (columns), as launch_flow_iter's d_xofs / d_xa
-    const float *xa;
-};
-struct CoopArgs {
-    int nlev, iterations;
-    CoopLevel lv[8];
-    float *flowA, *flowB;        // the workspace's ping-pong buffers
-    const float *init;           // OPTFLOW_USE_INITIAL_FLOW: the coarsest level's start (or nullptr); only read when prev == nullptr
-    const float *prev;           // final flow of the level above lv[0] (nullptr: lv[0] is the coarsest level)
-    int pw, ph;
-    float *final_out;            // the last step writes here instead of a ping-pong buffer (or nullptr)
-    float mul;
-    double scale;
-    unsigned long long *bar;     // device: bar[0] arrival counter (only ever grows), bar[1] give-up flag polled by the blocks
-    unsigned long long base;     // its value when this launch starts
-    unsigned *fail;              // page-locked host memory, device-visible: set when a wait gave up
-    unsigned long long timeout_ticks;   // per wait, in ticks of the 100 MHz wall clock
-};
-bool flow_iter_would_tile(int w, int h, int npairs, int winsize, int tile_mode);   // launch_flow_iter's choice, for the host
-int flow_levels_coop_capacity(int winsize);            // co-resident blocks on the current device (0: unsupported window)
-int flow_levels_coop_tiles(int w, int h, int winsize); // tiles of a level
-void launch_flow_levels_coop(hipStream_t s, const CoopArgs &a, int winsize, int blocks);
 // The same with the Gaussian window of OPTFLOW_FARNEBACK_GAUSSIAN (kernels_gauss.hip); h_kern: host pointer to the m+1 taps.
 bool flow_iter_gauss_supported(int winsize);
 void launch_flow_iter_gauss(hipStream_t s, const float *R, int fstep, const float *flow_in, float *flow_out, int w, int h,

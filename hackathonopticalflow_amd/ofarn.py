@@ -75,7 +75,6 @@ ABI = {
     "ofarn_calc": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _fp]),
     "ofarn_calc_reuse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, _ip]),
     "ofarn_calc_reuse_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
-    "ofarn_coop_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "ofarn_debug_device_scope": (C.c_int, [C.c_int, _ip, _ip]),
     "ofarn_debug_mapped_host_range": (C.c_int, [C.c_void_p, C.c_size_t]),
     "ofarn_calc_batch": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _u8p, _u8p]),
@@ -494,12 +493,6 @@ class FarnebackEngine:
         _check(self._lib.ofarn_calc_reuse(self._h, C.c_void_p(prev_a.ctypes.data), C.c_void_p(next_a.ctypes.data), w, h,
                                           prev_a.strides[0], next_a.strides[0], C.c_void_p(out.ctypes.data), C.byref(reused)))
         return (out, bool(reused.value)) if return_reused else out
-
-    def coop_info(self):
-        """(cooperative launches, fallbacks to separate launches) of this context's synchronous turns."""
-        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
-        _check(self._lib.ofarn_coop_info(self._h, C.byref(a), C.byref(b)))
-        return a.value, b.value
 
     def reuse_info(self):
         """(hits, misses) of calc_reuse on this context."""

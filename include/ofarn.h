@@ -168,15 +168,6 @@ int ofarn_stream_view_flow(ofarn_ctx *ctx, int w, int h, float *h_flow);
  * OPTFLOW_USE_INITIAL_FLOW (OFARN_E_UNSUPPORTED). */
 int ofarn_stream_submit(ofarn_ctx *ctx, const uint8_t *h_gray, int w, int h, int stride, float *h_flow);
 int ofarn_stream_wait(ofarn_ctx *ctx, int leave_in_flight);
-/* EXPERIMENT, off by default (ofarn_set_option "coop_levels": 0 = default; 1 = the levels whose tiles are all resident on the chip
- * at once; 2 = every level that takes the tile kernel; OFARN_COOP_LEVELS when the context is created).  A synchronous turn
- * (ofarn_stream_next*, ofarn_stream_next_view, ofarn_calc_reuse) then runs every iteration of the coarse levels of the pair --
- * twelve launches of a few microseconds each at 1080p / levels 5 -- in ONE launch behind a device-wide barrier whose waits are
- * bounded.  Bit-identical, and measured 40-50 us SLOWER per 1080p turn than the separate launches (a device-wide barrier costs as
- * much as a kernel boundary on this part), which is why it is off.  If a wait ever gives up (a grid that is not fully resident on a
- * shared GPU), the call reruns the iterations with separate launches before it returns and the context stops using the cooperative
- * launch.  *launches / *fallbacks count both. */
-int ofarn_coop_info(const ofarn_ctx *ctx, unsigned long long *launches, unsigned long long *fallbacks);
 /* Forgets the held frame: the next call primes again (a cut in the video, a seek: DenseOF.py:476-481 re-reads prev_gray). */
 int ofarn_stream_reset(ofarn_ctx *ctx);
 /* 1 if the session holds a frame of this size (the next ofarn_stream_next* call will produce a flow), else 0. */
@@ -327,7 +318,7 @@ int ofarn_reserve(ofarn_ctx *ctx, int w, int h, int n_pairs, int pairs_mode);
  * build + polynomial expansion on an internal stream beside the iteration chain; 0 off, 1 the chain waits for an event behind every
  * level's expansion, 2 = default: behind the coarsest level's and then every second one's), "push_blocks" (experiment, default 0 = hipMemcpyAsync: ofarn_stream_submit pushes a flow field to page-locked host memory with a
  * kernel of that many blocks), "debug_fail_wave" (test hook: the
- * (value+1)-th wave from now fails with OFARN_E_NOMEM; -1 = off), "coop_levels" (see ofarn_coop_info), "prof_dual" (per-kernel timing
+ * (value+1)-th wave from now fails with OFARN_E_NOMEM; -1 = off), "prof_dual" (per-kernel timing
  * without forcing the waves of a batch onto one stream), and
  * "box_order" (OFARN_BOX_ORDER): 0 = default, the box window of FarnebackUpdateFlow_Blur summed with restarted running sums (the
  * throughput kernels; oracle order OFO_BOX_BLOCKED); 1 = summed EXACTLY as optflowgf.cpp sums it -- one double running sum per

@@ -674,66 +674,6 @@ def test_pinned_source_frame_may_be_rewritten_after_the_next_submit(H, oracle):
         np.testing.assert_array_equal(outs[i], refs[i])
 
 
-@pytest.mark.parametrize("w,h,kw", [(320, 240, dict(levels=3)), (1920, 1080, dict(levels=5)), (333, 251, dict(levels=2, winsize=9, iterations=2)),
-                                    (640, 480, dict(levels=4, iterations=1)), (200, 150, dict(levels=2, flags=4))])
-def test_cooperative_coarse_levels_bit_exact(H, oracle, w, h, kw):
-    """VERDICT r3 next #4a.  Synchronous turns run every iteration of the coarse levels in ONE launch behind a bounded device-wide
-    barrier ("coop_levels" 1: levels whose tiles are all resident at once; 2: every tile-kernel level; 0: separate launches).  Same
-    arithmetic, same buffers: each setting equals the oracle bit for bit, through ofarn_stream_next, the view turn and ofarn_calc_reuse."""
-    fr = video(4, h, w, 61)
-    use_init = bool(kw.get("flags", 0) & 4)
-    zero = np.zeros((h, w, 2), np.float32)
-    refs = [oracle.farneback(fr[i], fr[i + 1], box_mode=oracle.BOX_BLOCKED, init_flow=zero if use_init else None, **kw) for i in range(3)]
-    for coop in (0, 1, 2):
-        with H.FarnebackEngine(w, h, 1, **kw) as eng:
-            eng.set_option("coop_levels", coop)
-            out = H.pinned_empty((h, w, 2))
-            assert eng.stream_next(fr[0], out) is None
-            for i in range(1, 4):
-                out[...] = 0
-                np.testing.assert_array_equal(eng.stream_next(fr[i], out), refs[i - 1])
-            launches, fallbacks = eng.coop_info()
-            assert fallbacks == 0
-            if coop == 0 or use_init:
-                assert launches == 0                                   # in/out flow turns keep the separate launches
-            elif kw.get("iterations", 3) * (kw["levels"] + 1) >= 2:
-                assert launches == 3, (coop, launches)
-            if not use_init:
-                eng.stream_reset()
-                assert eng.stream_next_view(fr[0]) is None
-                got = eng.stream_next_view(fr[1], danger=True, arrows=14)
-                np.testing.assert_array_equal(eng.stream_view_flow(w, h), refs[0])
-                np.testing.assert_array_equal(got["mask"], eng.danger_map(refs[0])[0])
-                np.testing.assert_array_equal(eng.calc_reuse(fr[1], fr[2]), refs[1])       # reuse: frame 1 is what the session holds
-                np.testing.assert_array_equal(eng.calc_reuse(fr[0], fr[1]), refs[0])       # miss: both frames again
-
-
-def test_cooperative_launch_that_gives_up_is_redone_with_separate_launches(H, oracle):
-    """The bounded wait of the cooperative launch: when a block gives up (here: the test hook raises the flag the blocks poll, as if
-    a wait had timed out on a GPU shared with someone else's resident kernels), every block leaves, the turn's result is garbage --
-    and the entry point, which looks at the flag behind its synchronisation, reruns the iterations with separate launches before it
-    returns.  The caller sees the oracle's flow; the context has stopped using cooperative launches."""
-    w, h, kw = 640, 480, dict(levels=4)
-    fr = video(5, h, w, 67)
-    refs = [oracle.farneback(fr[i], fr[i + 1], box_mode=oracle.BOX_BLOCKED, **kw) for i in range(4)]
-    with H.FarnebackEngine(w, h, 1, **kw) as eng:
-        out = H.pinned_empty((h, w, 2))
-        eng.stream_next(fr[0], out)
-        eng.set_option("coop_levels", 1)                        # off by default (measured slower than separate launches)
-        np.testing.assert_array_equal(eng.stream_next(fr[1], out), refs[0])
-        assert eng.coop_info() == (1, 0)
-        eng.set_option("debug_coop_fail", 1)                   # the next cooperative launch finds the flag raised at its first wait
-        out[...] = 0
-        np.testing.assert_array_equal(eng.stream_next(fr[2], out), refs[1])
-        assert eng.coop_info() == (2, 1)
-        np.testing.assert_array_equal(eng.stream_next(fr[3], out), refs[2])
-        assert eng.coop_info() == (2, 1)                        # no further cooperative launches on this context
-        np.testing.assert_array_equal(eng.calc_reuse(fr[3], fr[4]), refs[3])
-        eng.set_option("coop_levels", 1)                        # a caller may switch it back on
-        np.testing.assert_array_equal(eng.calc_reuse(fr[0], fr[1]), refs[0])
-        assert eng.coop_info()[0] > 2
-
-
 def test_calc_reuse_random_call_sequences(H):
     """ofarn_calc_reuse is a pure function of (prev, next) whatever happened on the context before: 120 random calls -- the loop's
     pattern (prev = last next), repeats, copies, in-place edits of the held frame, unrelated pairs, strided views, other entry points
