@@ -33,7 +33,7 @@ constexpr int TI_TW = OFARN_TILE_TW;
 // One tile: output pixels [x0, x0 + TW) x [yb, yb + B) of pair p.  sM: matrices of padded rows yb .. yb+2B-2 at columns x0-m ..
 // x0+TW+m-1 (clamped); sV: column sums of the B output rows.  (A persistent kernel that called this body tile after tile for every
 // iteration of the coarse levels behind a device-wide barrier was built in round 4 and measured 40-50 us slower per 1080p turn than
-// the separate launches: git tag r04-coop-levels-experiment, profiles/r04_coop_ab.txt.)
+// the separate launches: commit cfc2e1e (tag r04-coop-levels-experiment), profiles/r04_coop_ab.txt.)
 template <int M_, int MODE>   // MODE 0: flow_in == 0;  1: flow_in = upsample(coarse)*mul;  2: flow_in from HBM
 __device__ __forceinline__ void flow_iter_tile_body(float (&sM)[5][4 * M_ + 1][TI_TW + 2 * M_], double (&sV)[5][2 * M_ + 1][TI_TW + 2 * M_],
                                                     const float *__restrict__ R, int fstep, const float2 *__restrict__ flow_in,
