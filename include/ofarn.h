@@ -17,6 +17,13 @@
  * exceptions cross this boundary.  Every function returns OFARN_OK (0) or a negative error code
  * and leaves a message for ofarn_last_error() (thread local).
  *
+ * THE CONTRACT is seven entry points: ofarn_create, ofarn_calc, ofarn_calc_batch (+ _device), ofarn_grid_filter,
+ * ofarn_destroy, ofarn_last_error and the timing getter ofarn_last_device_ms.  Everything else in this header is one of
+ *   - the same path in the shape the reference's frame loop uses it (ofarn_stream_*, ofarn_calc_reuse) or across GPUs (ofarn_multi_*),
+ *   - the "next" rows of SURVEY 8(f) (front end, flags, visualisers, sparse LK),
+ *   - per-stage entry points and switches for the parity tests and measurements,
+ *   - extras outside the contract, grouped at the END of the file under their own banner.
+ *
  * Pointer naming: h_* = host memory, d_* = device (HBM) memory of the context's GPU.
  * A context is bound to one GPU and must not be used from two threads at once.
  *
